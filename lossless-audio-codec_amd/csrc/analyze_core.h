@@ -1,0 +1,686 @@
+// analyze_core.h -- the per-thread phases of the channel-block analysis kernel.
+//
+// One workgroup analyses one "slot" (a channel-segment of n <= CH*T samples) and produces exactly the
+// decisions Block::Encoder::encode makes before emitting bits (ref src/codec/block/encoder.cpp:313-552).
+// The reference walks every residual serially with stateful Rice models; here the same numbers come
+// from feed-forward array operations:
+//   * thread t owns the CH consecutive samples [t*CH, t*CH+CH); CH divides 32, so the reference's
+//     256-sample drift window and 96-sample micro window start on chunk boundaries and their sums are
+//     differences of block-scanned chunk prefixes;
+//   * the adaptive Rice parameter after sample j depends only on prefix sums of u = zigzag(residual)
+//     (Rice::adapt_k never feeds its result back into its state, ref src/codec/rice/rice.hpp:45-114),
+//     and is obtained without a division (kmean());
+//   * all 16 static-k and 13 initial-k costs come from bit-plane population counts:
+//     sum_j (u_j >> k) = sum_{b>=k} 2^(b-k) * C_b, with C_b counted by bit-sliced adders per thread,
+//     wave ballots per block, and group prefix tables per partition (ref block/encoder.cpp:121-188);
+//   * zero runs are resolved with a block prefix-max of "last non-zero index" and a 3-sample lookahead.
+//
+// The functions here are plain per-thread code (no cross-lane operations) so that the same text is
+// compiled into the HIP kernel (kernels.hip) and into the lock-step host simulator used by the CPU
+// tests (tests/native/sim_analyze.cpp).  Cross-thread steps (block scans, ballots, LDS atomics) live in
+// the drivers.
+#pragma once
+#include "lacx_types.h"
+#include "x87.h"
+
+namespace lacx {
+
+template <int CH_, int T_>
+struct Geo {
+    static constexpr int CH = CH_;
+    static constexpr int T = T_;
+    static constexpr int MAXN = CH_ * T_;
+    static constexpr int LV = (CH_ == 16) ? 5 : ((CH_ == 8) ? 4 : 3);  // bits of a count in 0..CH
+    static constexpr int TPG = 64 / CH_;      // threads per 64-sample group
+    static constexpr int NG = MAXN / 64;      // 64-sample groups
+    static constexpr int W256 = 256 / CH_;    // drift window, in chunks
+    static constexpr int W96 = 96 / CH_;      // micro window, in chunks
+    static constexpr int MAXP = (MAXN >= 8192) ? 8 : ((MAXN >= 4096) ? 7 : ((MAXN >= 2048) ? 6 : ((MAXN >= 1024) ? 5 : ((MAXN >= 512) ? 4 : 3))));
+    static constexpr int NSEG = (2 << MAXP) - 2;  // segments over all partition orders 1..MAXP
+    static_assert(32 % CH_ == 0, "chunk must divide the 96/256 windows");
+    static_assert(MAXN % 64 == 0, "whole groups");
+};
+
+// Where a slot's samples come from: a plain channel, or M/S derived on the fly
+// (ref src/codec/simd/neon.cpp:14-30: M = (L+R)>>1 arithmetic, S = L-R).
+struct SlotSrc {
+    const int32_t* a;
+    const int32_t* b;
+    int kind;  // CH_L/CH_R: read a; CH_M / CH_S: combine a (left) and b (right)
+};
+
+LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
+    const int32_t l = s.a[idx];
+    if (s.kind < CH_M) return l;
+    const int32_t r = s.b[idx];
+    if (s.kind == CH_M) return (int32_t)((uint32_t)l + (uint32_t)r) >> 1;
+    return (int32_t)((uint32_t)l - (uint32_t)r);
+}
+
+LACX_HD uint32_t zigzag32(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
+
+// Rice parameter of Rice::adapt_k / adapt_k_stateless before biasing:
+//   mean = (S + (c>>1)) / c ; k = mean <= 1 ? 0 : bit_width(mean-1)       (ref rice.hpp:68-71,
+//   block/encoder.cpp:72-77) == the smallest k with mean <= 2^k, i.e. with (X - c) < (c << k), X = S + (c>>1).
+LACX_HD uint32_t kmean(uint64_t S, uint32_t c) {
+    const uint64_t X = S + (c >> 1);
+    if (X < 2ull * c) return 0;
+    const uint64_t Y = X - c;  // >= c
+    const int g = clz64((uint64_t)c) - clz64(Y);  // bit_width(Y) - bit_width(c) >= 0
+    return (uint32_t)g + ((Y >> g) >= c ? 1u : 0u);
+}
+
+LACX_HD uint64_t rice_cost(uint32_t u, uint32_t k) {  // ref block/encoder.cpp:67-70
+    return (uint64_t)((k >= 31u) ? 0u : (u >> k)) + 1u + k;
+}
+
+struct SegInfo {
+    uint64_t sbits;  // static Rice bits at sk
+    uint8_t ak;      // adaptive initial k (estimate_initial_k)
+    uint8_t sk;      // static k (estimate_static_k)
+    uint8_t pad[6];
+};
+
+template <class G>
+struct Smem {
+    uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate; bits 30/31 = micro flags
+    uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
+    int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
+    uint32_t tabF[G::T + 1];  // in: packed chunk flag counts; after scan: exclusive prefix
+    uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
+    uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
+    unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
+    uint64_t wtotP[16];  // per-wave totals used by the block scans
+    int32_t wtotZ[16];
+    uint32_t wtotF[16];
+    // running best candidate (written by thread 0)
+    uint64_t best_bits, best_rice, best_zr, best_bin, best_static;
+    uint32_t best_k0, best_sk, best_hasrun;
+    int32_t best_cand;
+    uint32_t cur_k0;
+    LpcSet lpc;
+    // partition search
+    uint32_t grp[15][G::NG + 1];  // packed (two 16-bit fields) plane counts per 64-sample group -> prefix
+    SegInfo seginfo[G::NSEG];
+    unsigned long long segacc[G::NSEG][3];
+    uint32_t segrun[G::NSEG];
+    uint8_t choice[G::NSEG];
+    unsigned long long pbits[G::MAXP + 1];
+};
+
+template <class G>
+struct Thread {
+    int tid;
+    int a;       // first sample of the chunk
+    uint32_t n;  // samples in the slot
+    int32_t xh[G::CH + 12];  // xh[12 + i] = x[a + i]; xh[0..11] = history (0 before the slot start)
+    uint32_t u[G::CH];
+    uint32_t kf[G::CH];      // km | is_large << 8 | is_zero << 9
+    uint32_t cs[G::LV];      // bit-sliced per-plane counts of this chunk
+    unsigned long long crice, cbin, czr;  // chunk partial costs
+    uint32_t chasrun;
+};
+
+// ---------------------------------------------------------------------------------------------
+// sample load
+// ---------------------------------------------------------------------------------------------
+template <class G>
+LACX_HD void load_chunk(Thread<G>& th, const SlotSrc& src, int64_t start, uint32_t n, int tid) {
+    th.tid = tid;
+    th.a = tid * G::CH;
+    th.n = n;
+#pragma unroll
+    for (int i = 0; i < G::CH + 12; ++i) {
+        const int64_t j = (int64_t)th.a - 12 + i;
+        th.xh[i] = (j >= 0 && j < (int64_t)n) ? slot_fetch(src, start + j) : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// residuals.  cand 0..4 fixed orders (ref block/encoder.cpp:265-295), 5 FIR {3,-1}>>2 (:297-309),
+// 6..10 LPC orders 4..12 with open-loop Q15 prediction (ref lpc/lpc.cpp:38-61).
+// ---------------------------------------------------------------------------------------------
+template <class G>
+LACX_HD void residual_chunk(Thread<G>& th, int cand, const LpcSet& lpc) {
+    const int32_t* x = th.xh + 12;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const int j = th.a + i;
+        int32_t r;
+        if (cand <= 4) {
+            int64_t pred = 0;
+            if (j >= cand) {
+                switch (cand) {
+                    case 1: pred = x[i - 1]; break;
+                    case 2: pred = 2LL * x[i - 1] - x[i - 2]; break;
+                    case 3: pred = 3LL * x[i - 1] - 3LL * x[i - 2] + x[i - 3]; break;
+                    case 4: pred = 4LL * x[i - 1] - 6LL * x[i - 2] + 4LL * x[i - 3] - x[i - 4]; break;
+                    default: break;
+                }
+            }
+            r = (int32_t)((int64_t)x[i] - pred);
+        } else if (cand == 5) {
+            int64_t pred = 0;
+            if (j >= 2) pred = (3LL * (int64_t)x[i - 1] - (int64_t)x[i - 2]) >> 2;
+            r = (int32_t)((int64_t)x[i] - pred);
+        } else {
+            const int ci = cand - 6;
+            const int ord = lpc.used[ci];
+            int64_t acc = 0;
+#pragma unroll
+            for (int t = 1; t <= 12; ++t) {
+                if (t <= ord) acc += (int64_t)lpc.coef[ci][t] * (int64_t)x[i - t];
+            }
+            r = (int32_t)((int64_t)x[i] - (acc >> 15));
+        }
+        th.u[i] = ((uint32_t)j < th.n) ? zigzag32(r) : 0u;
+    }
+}
+
+// bit-sliced add of two W-bit counters held as W words (bit b of word l = bit l of the count of plane b)
+template <int W>
+LACX_HD void sliced_add(const uint32_t* a, const uint32_t* b, uint32_t* out /* W+1 words */) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int l = 0; l < W; ++l) {
+        const uint32_t x = a[l] ^ b[l];
+        out[l] = x ^ carry;
+        carry = (a[l] & b[l]) | (x & carry);
+    }
+    out[W] = carry;
+}
+
+// Phase R: chunk sum, last non-zero index, bit-sliced plane counts of th.u[].
+template <class G>
+LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh) {
+    uint64_t s = 0;
+    int32_t lastnz = -1;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        s += th.u[i];
+        if (th.u[i] != 0) lastnz = th.a + i;
+    }
+    sh.tabP[th.tid] = s;
+    sh.tabNZ[th.tid] = lastnz;
+    // plane counts: pairwise tree of bit-sliced adders
+    if (G::CH == 16) {
+        uint32_t l1[8][2], l2[4][3], l3[2][4], l4[5];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sliced_add<1>(&th.u[2 * i], &th.u[2 * i + 1], l1[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sliced_add<2>(l1[2 * i], l1[2 * i + 1], l2[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sliced_add<3>(l2[2 * i], l2[2 * i + 1], l3[i]);
+        sliced_add<4>(l3[0], l3[1], l4);
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) th.cs[l] = l4[l];
+    } else if (G::CH == 4) {
+        uint32_t l1[2][2], l2[3];
+        sliced_add<1>(&th.u[0], &th.u[1], l1[0]);
+        sliced_add<1>(&th.u[2], &th.u[3], l1[1]);
+        sliced_add<2>(l1[0], l1[1], l2);
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) th.cs[l] = l2[l];
+    }
+}
+
+// Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.
+LACX_HD void planes_to_ksums(const uint32_t* C, uint64_t* A, int kmax) {
+    uint64_t acc = 0;
+    for (int b = 29; b >= 0; --b) {
+        acc = (acc << 1) + C[b];
+        if (b <= kmax) A[b] = acc;
+    }
+}
+
+// estimate_initial_k (ref block/encoder.cpp:121-158): argmin over k=0..12 of sum (u>>k) + m*(1+k).
+LACX_HD uint32_t pick_initial_k(const uint64_t* A, uint32_t m) {
+    uint32_t best_k = 0;
+    uint64_t best = ~0ull;
+    for (uint32_t k = 0; k <= 12; ++k) {
+        const uint64_t c = A[k] + (uint64_t)m * (1u + k);
+        if (c < best) {
+            best = c;
+            best_k = k;
+        }
+    }
+    return best_k;
+}
+
+// estimate_static_k + estimate_static_rice_bits (ref block/encoder.cpp:160-188).
+LACX_HD uint32_t pick_static_k(const uint64_t* A, uint32_t m, uint64_t* bits) {
+    uint32_t best_k = 0;
+    uint64_t best = ~0ull;
+    for (uint32_t k = 0; k <= 15; ++k) {
+        const uint64_t c = A[k] + (uint64_t)m * (1u + k);
+        if (c < best) {
+            best = c;
+            best_k = k;
+        }
+    }
+    *bits = best;
+    return best_k;
+}
+
+// Phase A: unbiased k after every sample, micro-window flags (ref rice.hpp:68-80).
+template <class G>
+LACX_HD void phase_a(Thread<G>& th, Smem<G>& sh) {
+    uint64_t P = sh.tabP[th.tid];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t j = (uint32_t)(th.a + i);
+        if (j < th.n) {
+            P += th.u[i];
+            const uint32_t km = kmean(P, j + 1u);
+            const uint32_t q = (km >= 31u) ? 0u : (th.u[i] >> km);
+            const uint32_t fl = q > 3u, fz = q == 0u;
+            th.kf[i] = km | (fl << 8) | (fz << 9);
+            sh.u[j] = th.u[i] | (fl << 30) | (fz << 31);
+            cnt += fl + (fz << 16);
+        } else {
+            th.kf[i] = 0;
+        }
+    }
+    sh.tabF[th.tid] = cnt;
+}
+
+// Plain (flag-free) copy of the chunk's u into shared memory, for the partition search.
+template <class G>
+LACX_HD void store_u_plain(const Thread<G>& th, Smem<G>& sh) {
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t j = (uint32_t)(th.a + i);
+        if (j < th.n) sh.u[j] = th.u[i];
+    }
+}
+
+// zero-run helpers -----------------------------------------------------------------------------
+// ext[i] for i in [0, CH+3): is sample a+i a non-zero or outside [.., limit) ?
+template <class G>
+LACX_HD void load_lookahead(const Thread<G>& th, const Smem<G>& sh, uint32_t* la) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t j = (uint32_t)(th.a + G::CH + i);
+        la[i] = (j < th.n) ? (sh.u[j] & 0x3FFFFFFFu) : 1u;
+    }
+}
+
+// Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
+// (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
+template <class G>
+LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
+    const int t = th.tid;
+    uint64_t P = sh.tabP[t];                                   // P_{a-1}
+    uint64_t W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;    // P_{a-1-256}
+    uint32_t F = sh.tabF[t];                                   // flag counts over [0, a-1]
+    uint32_t F96 = (t >= G::W96) ? sh.tabF[t - G::W96] : 0;    // ... over [0, a-1-96]
+    uint32_t la[3];
+    load_lookahead(th, sh, la);
+    uint32_t kprev = k0;
+    if (th.a > 0 && (uint32_t)th.a < th.n) {
+        // k returned after sample a-1 (count c = a)
+        const uint32_t c = (uint32_t)th.a;
+        const uint32_t km = kmean(P, c);
+        int bias = 0;
+        const uint64_t X = P + (c >> 1);
+        if (c > 256u && X >= c) {
+            const uint64_t L = ((P - W) + 128u) >> 8;
+            const uint64_t U = (3u * L + 3u) >> 2;
+            const uint64_t D = L + (L + 3u) / 3u + 1u;
+            if (X < U * c) {
+                bias = 1;
+            } else if (X >= D * c) {
+                bias = -1;
+            }
+        }
+        if (c >= 96u) {
+            const uint32_t d = F - F96;
+            const uint32_t large = d & 0xFFFFu, zero = d >> 16;
+            if (large * 4u >= 288u) {
+                bias = (bias + 1 < 1) ? bias + 1 : 1;
+            } else if (zero * 5u >= 384u) {
+                bias = (bias - 1 > -1) ? bias - 1 : -1;
+            }
+        }
+        int bk = (int)km + bias;
+        bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
+        kprev = (uint32_t)bk;
+    }
+    // zeros ending just before the chunk
+    int32_t f = th.a - 1 - sh.tabNZ[t];
+    unsigned long long rice = 0, bin = 0, zr = 0;
+    uint32_t hasrun = 0;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t j = (uint32_t)(th.a + i);
+        if (j < th.n) {
+            const uint32_t u = th.u[i];
+            const uint32_t kin = (j == 0) ? k0 : kprev;
+            const uint64_t rc = rice_cost(u, kin);
+            rice += rc;
+            bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
+            // run structure
+            const bool z = (u == 0);
+            f = z ? f + 1 : 0;
+            // next three samples: non-zero or outside the block?
+            const uint32_t n1 = (i + 1 < G::CH) ? (((uint32_t)(j + 1) < th.n) ? th.u[(i + 1 < G::CH) ? i + 1 : 0] : 1u) : la[(i + 1 - G::CH) < 0 ? 0 : (i + 1 - G::CH)];
+            const uint32_t n2 = (i + 2 < G::CH) ? (((uint32_t)(j + 2) < th.n) ? th.u[(i + 2 < G::CH) ? i + 2 : 0] : 1u) : la[(i + 2 - G::CH) < 0 ? 0 : (i + 2 - G::CH)];
+            const uint32_t n3 = (i + 3 < G::CH) ? (((uint32_t)(j + 3) < th.n) ? th.u[(i + 3 < G::CH) ? i + 3 : 0] : 1u) : la[(i + 3 - G::CH) < 0 ? 0 : (i + 3 - G::CH)];
+            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+            const bool in4 = z && (f + ahead >= 4);
+            if (!in4) {
+                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+                zr += 2u + ((u > esc) ? 32u : rc);
+            } else if (n1 != 0) {  // last sample of a run of length f >= 4
+                zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
+                hasrun = 1;
+            }
+            // state after sample j -> k for sample j+1
+            P += u;
+            if (j >= 256u) W += sh.u[j - 256u] & 0x3FFFFFFFu;
+            F += ((th.kf[i] >> 8) & 1u) + (((th.kf[i] >> 9) & 1u) << 16);
+            if (j >= 96u) {
+                const uint32_t w = sh.u[j - 96u];
+                F96 += ((w >> 30) & 1u) + ((w >> 31) << 16);
+            }
+            const uint32_t c = j + 1u;
+            const uint32_t km = th.kf[i] & 0xFFu;
+            int bias = 0;
+            const uint64_t X = P + (c >> 1);
+            if (c > 256u && X >= c) {
+                const uint64_t L = ((P - W) + 128u) >> 8;
+                const uint64_t U = (3u * L + 3u) >> 2;
+                const uint64_t D = L + (L + 3u) / 3u + 1u;
+                if (X < U * c) {
+                    bias = 1;
+                } else if (X >= D * c) {
+                    bias = -1;
+                }
+            }
+            if (c >= 96u) {
+                const uint32_t d = F - F96;
+                const uint32_t large = d & 0xFFFFu, zero = d >> 16;
+                if (large * 4u >= 288u) {
+                    bias = (bias + 1 < 1) ? bias + 1 : 1;
+                } else if (zero * 5u >= 384u) {
+                    bias = (bias - 1 > -1) ? bias - 1 : -1;
+                }
+            }
+            int bk = (int)km + bias;
+            bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
+            kprev = (uint32_t)bk;
+        }
+    }
+    th.crice = rice;
+    th.cbin = bin;
+    th.czr = zr;
+    th.chasrun = hasrun;
+}
+
+// Candidate scoring by thread 0 once the block reductions are in shared memory
+// (ref block/encoder.cpp:337-359).  Returns nothing; updates sh.best_*.
+template <class G>
+LACX_HD void score_candidate(Smem<G>& sh, int cand, uint32_t n, int zero_run, uint32_t k0,
+                             const uint32_t* planeTot, const unsigned long long* acc) {
+    uint64_t A[16];
+    planes_to_ksums(planeTot, A, 15);
+    uint64_t sbits;
+    const uint32_t sk = pick_static_k(A, n, &sbits);
+    const uint64_t rice = acc[0], bin = acc[1];
+    const uint32_t hasrun = acc[3] != 0;
+    const uint64_t zr = (zero_run && hasrun) ? acc[2] : rice;
+    uint64_t a = rice < sbits ? rice : sbits;
+    uint64_t b = zr < bin ? zr : bin;
+    const uint64_t best = a < b ? a : b;
+    if (sh.best_cand < 0 || best < sh.best_bits) {
+        sh.best_cand = cand;
+        sh.best_bits = best;
+        sh.best_rice = rice;
+        sh.best_zr = zr;
+        sh.best_bin = bin;
+        sh.best_static = sbits;
+        sh.best_k0 = k0;
+        sh.best_sk = sk;
+        sh.best_hasrun = hasrun;
+    }
+}
+
+LACX_HD uint32_t initial_k_from_planes(const uint32_t* planes256, uint32_t n) {
+    uint64_t A[16];
+    planes_to_ksums(planes256, A, 12);
+    return pick_initial_k(A, n < 256u ? n : 256u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// partition search (ref block/encoder.cpp:486-552) on the winning residual
+// ---------------------------------------------------------------------------------------------
+LACX_HD int max_partition_order(uint32_t n) {  // ref block/encoder.cpp:93-101
+    int mp = 0;
+    for (int p = 1; p <= kMaxPartitionOrder; ++p) {
+        if ((n >> p) < (uint32_t)kMinPartition) break;
+        mp = p;
+    }
+    return mp;
+}
+
+// Per-thread packed plane counts (two planes per word: plane w in bits 0..15, plane w+15 in 16..31).
+template <class G>
+LACX_HD void packed_planes(const Thread<G>& th, uint32_t* words /* 15 */) {
+#pragma unroll
+    for (int w = 0; w < 15; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) {
+            v += (((th.cs[l] >> w) & 1u) << l) + (((th.cs[l] >> (w + 15)) & 1u) << (16 + l));
+        }
+        words[w] = v;
+    }
+}
+
+// sum_j (u_j >> k) over [s, e), k = 0..15, from the group prefix table + direct sums at ragged ends.
+template <class G>
+LACX_HD void range_ksums(const Smem<G>& sh, uint32_t s, uint32_t e, uint64_t* A) {
+    for (int k = 0; k < 16; ++k) A[k] = 0;
+    const uint32_t gs = (s + 63u) >> 6, ge = e >> 6;
+    if (gs < ge) {
+        uint32_t C[30];
+        for (int w = 0; w < 15; ++w) {
+            const uint32_t d = sh.grp[w][ge] - sh.grp[w][gs];
+            C[w] = d & 0xFFFFu;
+            C[w + 15] = d >> 16;
+        }
+        planes_to_ksums(C, A, 15);
+        for (uint32_t j = s; j < (gs << 6); ++j) {
+            const uint32_t u = sh.u[j];
+            for (int k = 0; k < 16; ++k) A[k] += u >> k;
+        }
+        for (uint32_t j = ge << 6; j < e; ++j) {
+            const uint32_t u = sh.u[j];
+            for (int k = 0; k < 16; ++k) A[k] += u >> k;
+        }
+    } else {
+        for (uint32_t j = s; j < e; ++j) {
+            const uint32_t u = sh.u[j];
+            for (int k = 0; k < 16; ++k) A[k] += u >> k;
+        }
+    }
+}
+
+LACX_HD void seg_bounds(uint32_t n, int p, uint32_t part, uint32_t* s, uint32_t* e) {
+    const uint32_t base = n >> p, parts = 1u << p;  // ref block/encoder.cpp:103-119
+    *s = part * base;
+    *e = (part + 1u == parts) ? n : (*s + base);
+}
+
+// One thread evaluates the static and initial k of one segment.
+template <class G>
+LACX_HD void seg_static_eval(Smem<G>& sh, uint32_t n, int p, uint32_t part) {
+    uint32_t s, e;
+    seg_bounds(n, p, part, &s, &e);
+    const uint32_t len = e - s;
+    uint64_t A[16];
+    range_ksums(sh, s, e, A);
+    SegInfo si;
+    si.sk = (uint8_t)pick_static_k(A, len, &si.sbits);
+    const uint32_t m = len < 256u ? len : 256u;
+    if (m != len) range_ksums(sh, s, s + m, A);
+    si.ak = (uint8_t)pick_initial_k(A, m);
+    for (int i = 0; i < 6; ++i) si.pad[i] = 0;
+    sh.seginfo[(2u << (p - 1)) - 2u + part] = si;
+}
+
+// Stateless adaptive pass of one partition order over the thread's chunk
+// (ref block/encoder.cpp:201-263 with adapt_k_stateless :72-77).  Partial sums leave through `flush`.
+template <class G, class Flush>
+LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush&& flush) {
+    if ((uint32_t)th.a >= th.n) return;
+    const uint32_t n = th.n;
+    const uint32_t base = n >> p, parts = 1u << p;
+    uint32_t part = (uint32_t)th.a / base;
+    if (part >= parts) part = parts - 1u;
+    uint32_t s = part * base;
+    uint32_t e = (part + 1u == parts) ? n : s + base;
+    const uint32_t segbase = (2u << (p - 1)) - 2u;
+    uint64_t P = sh.tabP[th.tid];  // P_{a-1}
+    uint64_t Pseg;                 // P_{s-1}
+    {
+        const uint32_t cs = s / G::CH;
+        Pseg = sh.tabP[cs];
+        for (uint32_t j = cs * G::CH; j < s; ++j) Pseg += sh.u[j];
+    }
+    uint32_t la[3];
+    load_lookahead(th, sh, la);
+    int32_t lastnz = sh.tabNZ[th.tid];
+    if (lastnz < (int32_t)s - 1) lastnz = (int32_t)s - 1;
+    int32_t f = th.a - 1 - lastnz;
+    unsigned long long rice = 0, bin = 0, zr = 0;
+    uint32_t hasrun = 0;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t j = (uint32_t)(th.a + i);
+        if (j < n) {
+            if (j == e) {  // partition boundary inside the chunk
+                flush(segbase + part, rice, bin, zr, hasrun);
+                rice = bin = zr = 0;
+                hasrun = 0;
+                ++part;
+                s = e;
+                e = (part + 1u == parts) ? n : s + base;
+                Pseg = P;
+                f = 0;
+            }
+            const uint32_t u = th.u[i];
+            const uint32_t kin = (j == s) ? (uint32_t)sh.seginfo[segbase + part].ak : kmean(P - Pseg, j - s);
+            const uint64_t rc = rice_cost(u, kin);
+            rice += rc;
+            bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
+            const bool z = (u == 0);
+            f = z ? f + 1 : 0;
+            const uint32_t x1 = (i + 1 < G::CH) ? th.u[(i + 1 < G::CH) ? i + 1 : 0] : la[(i + 1 - G::CH) < 0 ? 0 : (i + 1 - G::CH)];
+            const uint32_t x2 = (i + 2 < G::CH) ? th.u[(i + 2 < G::CH) ? i + 2 : 0] : la[(i + 2 - G::CH) < 0 ? 0 : (i + 2 - G::CH)];
+            const uint32_t x3 = (i + 3 < G::CH) ? th.u[(i + 3 < G::CH) ? i + 3 : 0] : la[(i + 3 - G::CH) < 0 ? 0 : (i + 3 - G::CH)];
+            const uint32_t n1 = (j + 1u < e) ? x1 : 1u;
+            const uint32_t n2 = (j + 2u < e) ? x2 : 1u;
+            const uint32_t n3 = (j + 3u < e) ? x3 : 1u;
+            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+            const bool in4 = z && (f + ahead >= 4);
+            if (!in4) {
+                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+                zr += 2u + ((u > esc) ? 32u : rc);
+            } else if (n1 != 0) {
+                zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
+                hasrun = 1;
+            }
+            P += u;
+        }
+    }
+    flush(segbase + part, rice, bin, zr, hasrun);
+}
+
+// Mode choice of one partition (ref block/encoder.cpp:495-525); returns bits, writes (mode<<5)|k.
+template <class G>
+LACX_HD uint64_t seg_choose(Smem<G>& sh, uint32_t idx, int zero_run) {
+    const SegInfo si = sh.seginfo[idx];
+    const uint64_t normal = sh.segacc[idx][0], bin = sh.segacc[idx][1];
+    const bool allow_zr = zero_run && sh.segrun[idx] != 0;
+    const uint64_t zr = allow_zr ? sh.segacc[idx][2] : normal;
+    uint32_t mode = 0, k = si.ak;
+    uint64_t bits = normal;
+    if (allow_zr && zr < bits) {
+        mode = 1;
+        bits = zr;
+    }
+    if (bin < bits) {
+        mode = 2;
+        bits = bin;
+    }
+    if (si.sbits < bits || si.sbits <= bits + bits / 20u) {
+        mode = 3;
+        k = si.sk;
+        bits = si.sbits;
+    }
+    sh.choice[idx] = (uint8_t)((mode << 5) | k);
+    return bits;
+}
+
+// Final decisions by thread 0 (ref block/encoder.cpp:421-484, 527-552, 773-795).
+template <class G>
+LACX_HD void finalize_plan(Smem<G>& sh, uint32_t n, int zero_run, int max_p, ChannelPlan* out) {
+    const int cand = sh.best_cand;
+    uint8_t ptype, order;
+    if (cand <= 4) {
+        ptype = 0;
+        order = (uint8_t)cand;
+    } else if (cand == 5) {
+        ptype = 1;
+        order = 2;
+    } else {
+        ptype = 2;
+        order = sh.lpc.used[cand - 6];  // chosen_order: used <= cand <= max_valid_order
+    }
+    out->valid = 1;
+    out->predictor_type = ptype;
+    out->order = order;
+    for (int i = 0; i < 12; ++i) out->coef[i] = (cand >= 6) ? sh.lpc.coef[cand - 6][i + 1] : (int16_t)0;
+    // unpartitioned mode (ref :432-456)
+    const bool allow_zr = zero_run && sh.best_hasrun;
+    uint32_t mode = 0, k = sh.best_k0;
+    uint64_t bits = sh.best_rice;
+    if (allow_zr && sh.best_zr <= bits) {
+        bits = sh.best_zr;
+        mode = 1;
+    }
+    if (sh.best_bin < bits) {
+        bits = sh.best_bin;
+        mode = 2;
+    }
+    if (sh.best_static < bits) {
+        bits = sh.best_static;
+        mode = 3;
+        k = sh.best_sk;
+    }
+    uint64_t best_total = bits + 8u + 7u;
+    best_total += (8u - (best_total & 7u)) & 7u;
+    int best_p = 0;
+    for (int p = 1; p <= max_p; ++p) {
+        uint64_t total = sh.pbits[p] + 8u + 7ull * (1u << p);
+        total += (8u - (total & 7u)) & 7u;
+        const uint64_t margin = best_total / 20u;
+        if (total < best_total || (total <= best_total + margin && best_p == 0)) {
+            best_total = total;
+            best_p = p;
+        }
+    }
+    out->partition_order = (uint8_t)best_p;
+    out->total_bits = best_total;
+    out->payload_bytes = (uint32_t)((16u + (ptype == 2 ? 16u * order : 0u) + best_total) >> 3);
+    if (best_p == 0) {
+        out->part_mode_k[0] = (uint8_t)((mode << 5) | k);
+    } else {
+        const uint32_t parts = 1u << best_p, segbase = (2u << (best_p - 1)) - 2u;
+        for (uint32_t i = 0; i < parts; ++i) out->part_mode_k[i] = sh.choice[segbase + i];
+    }
+}
+
+}  // namespace lacx

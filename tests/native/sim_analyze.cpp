@@ -1,0 +1,195 @@
+// tests/native/sim_analyze.cpp -- TEST INFRASTRUCTURE: lock-step host simulation of the analysis kernel.
+//
+// Runs the very per-thread phase functions the HIP kernel is built from (csrc/analyze_core.h), one
+// "thread" after the other between the points where the kernel has a workgroup barrier, with the
+// cross-thread steps (block scans, plane-count reductions, LDS atomics) replaced by their sequential
+// definitions.  This lets the CPU test-suite check the data-parallel reformulation against the oracle
+// without a GPU.  It is not part of the product and is not a fallback: nothing under
+// lossless-audio-codec_amd/ links or loads it.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "analyze_core.h"
+
+using namespace lacx;
+
+namespace {
+
+void autocorr13(const int32_t* x, uint32_t n, int64_t* r) {
+    for (int k = 0; k <= 12; ++k) {
+        int64_t s = 0;
+        for (uint32_t i = (uint32_t)k; i < n; ++i) s += (int64_t)x[i] * (int64_t)x[i - (uint32_t)k];
+        r[k] = s;
+    }
+}
+
+template <class G>
+void scans_after_r(Smem<G>& sh) {
+    uint64_t run = 0;
+    int32_t mx = -1;
+    for (int t = 0; t < G::T; ++t) {
+        const uint64_t v = sh.tabP[t];
+        const int32_t z = sh.tabNZ[t];
+        sh.tabP[t] = run;
+        sh.tabNZ[t] = mx;
+        run += v;
+        if (z > mx) mx = z;
+    }
+    sh.tabP[G::T] = run;
+    sh.tabNZ[G::T] = mx;
+}
+
+template <class G>
+void plane_totals(Smem<G>& sh, const std::vector<Thread<G>>& th) {
+    for (int b = 0; b < 32; ++b) sh.planeTot[0][b] = sh.planeTot256[0][b] = 0;
+    for (int t = 0; t < G::T; ++t) {
+        for (int l = 0; l < G::LV; ++l) {
+            for (int b = 0; b < 30; ++b) {
+                const uint32_t bit = (th[t].cs[l] >> b) & 1u;
+                sh.planeTot[0][b] += bit << l;
+                if (t < G::W256) sh.planeTot256[0][b] += bit << l;
+            }
+        }
+    }
+}
+
+template <class G>
+int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, ChannelPlan* out) {
+    if (n == 0 || n > (uint32_t)G::MAXN) return 1;
+    Smem<G>* shp = new Smem<G>;
+    Smem<G>& sh = *shp;
+    std::memset(shp, 0, sizeof(Smem<G>));
+    std::vector<Thread<G>> th(G::T);
+    SlotSrc src{x, nullptr, CH_L};
+    for (int t = 0; t < G::T; ++t) load_chunk(th[t], src, 0, n, t);
+    int64_t r[13];
+    autocorr13(x, n, r);
+    const int max_valid_order = (n > 1) ? (int)((n - 1 < 32u) ? n - 1 : 32u) : 0;
+    levinson_candidates(r, max_valid_order, sh.lpc.coef, sh.lpc.used);
+    sh.best_cand = -1;
+    for (int cand = 0; cand <= 10; ++cand) {
+        if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;
+        for (int t = 0; t < G::T; ++t) {
+            residual_chunk(th[t], cand, sh.lpc);
+            phase_r(th[t], sh);
+        }
+        scans_after_r(sh);
+        plane_totals(sh, th);
+        const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
+        for (int t = 0; t < G::T; ++t) phase_a(th[t], sh);
+        {
+            uint32_t run = 0;
+            for (int t = 0; t < G::T; ++t) {
+                const uint32_t v = sh.tabF[t];
+                sh.tabF[t] = run;
+                run += v;
+            }
+            sh.tabF[G::T] = run;
+        }
+        sh.acc[0][0] = sh.acc[0][1] = sh.acc[0][2] = sh.acc[0][3] = 0;
+        for (int t = 0; t < G::T; ++t) {
+            phase_b(th[t], sh, k0);
+            if ((uint32_t)th[t].a < n) {
+                sh.acc[0][0] += th[t].crice;
+                sh.acc[0][1] += th[t].cbin;
+                sh.acc[0][2] += th[t].czr;
+                sh.acc[0][3] += th[t].chasrun;
+            }
+        }
+        score_candidate(sh, cand, n, zero_run, k0, sh.planeTot[0], sh.acc[0]);
+    }
+    // partition search on the winner
+    const int best = sh.best_cand;
+    for (int t = 0; t < G::T; ++t) {
+        residual_chunk(th[t], best, sh.lpc);
+        phase_r(th[t], sh);
+        store_u_plain(th[t], sh);
+    }
+    scans_after_r(sh);
+    int max_p = 0;
+    if (partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
+    if (max_p > 0) {
+        for (int w = 0; w < 15; ++w)
+            for (int g = 0; g <= G::NG; ++g) sh.grp[w][g] = 0;
+        for (int t = 0; t < G::T; ++t) {
+            uint32_t words[15];
+            packed_planes(th[t], words);
+            for (int w = 0; w < 15; ++w) sh.grp[w][t / G::TPG] += words[w];
+        }
+        for (int w = 0; w < 15; ++w) {
+            uint32_t run = 0;
+            for (int g = 0; g <= G::NG; ++g) {
+                const uint32_t v = sh.grp[w][g];
+                sh.grp[w][g] = run;
+                run += v;
+            }
+        }
+        for (int p = 1; p <= max_p; ++p)
+            for (uint32_t part = 0; part < (1u << p); ++part) seg_static_eval(sh, n, p, part);
+        for (int i = 0; i < G::NSEG; ++i) {
+            sh.segacc[i][0] = sh.segacc[i][1] = sh.segacc[i][2] = 0;
+            sh.segrun[i] = 0;
+        }
+        for (int t = 0; t < G::T; ++t) {
+            for (int p = 1; p <= max_p; ++p) {
+                partition_pass(th[t], sh, p,
+                               [&](uint32_t idx, unsigned long long rc, unsigned long long bn,
+                                   unsigned long long zr, uint32_t hr) {
+                                   sh.segacc[idx][0] += rc;
+                                   sh.segacc[idx][1] += bn;
+                                   sh.segacc[idx][2] += zr;
+                                   sh.segrun[idx] |= hr;
+                               });
+            }
+        }
+        for (int p = 1; p <= max_p; ++p) {
+            sh.pbits[p] = 0;
+            const uint32_t segbase = (2u << (p - 1)) - 2u;
+            for (uint32_t part = 0; part < (1u << p); ++part) sh.pbits[p] += seg_choose(sh, segbase + part, zero_run);
+        }
+    }
+    std::memset(out, 0, sizeof(*out));
+    finalize_plan(sh, n, zero_run, max_p, out);
+    delete shp;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
+int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, ChannelPlan* out) {
+    if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, out);
+    return run_sim<Geo<4, 64>>(x, n, zero_run, partitioning, out);
+}
+
+// kmean() against the division it replaces; returns the number of mismatches.
+uint64_t sim_kmean_check(uint64_t seed, uint64_t iters) {
+    uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (uint64_t i = 0; i < iters; ++i) {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        const uint32_t c = 1u + (uint32_t)((s >> 8) % 16384u);
+        const int sh = (int)((s >> 40) % 46u);
+        uint64_t S = (s * 0xD6E8FEB86659FD93ull) >> (63 - sh);
+        if (i % 7 == 0) S = (uint64_t)c * ((s >> 20) % 70000u) + ((s >> 3) % 3u) - 1u + (c >> 1);  // near k boundaries
+        if ((int64_t)S < 0) S = 0;
+        const uint64_t mean = (S + (c >> 1)) / c;
+        uint32_t k = 0;
+        if (mean > 1) {
+            uint64_t v = mean - 1;
+            while (v) {
+                ++k;
+                v >>= 1;
+            }
+            if (k > 31) k = 31;
+        }
+        if (mean < (1ull << 31) && kmean(S, c) != k) ++bad;
+    }
+    return bad;
+}
+}

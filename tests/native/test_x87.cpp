@@ -1,0 +1,120 @@
+// Host check of csrc/x87.h against the machine's real x87 long double (test infrastructure).
+// Build: g++ -O2 -std=c++17 -I lossless-audio-codec_amd/csrc -I oracle tests/native/test_x87.cpp oracle/lac_oracle.c
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "x87.h"
+extern "C" {
+#include "lac_oracle.h"
+}
+using namespace lacx;
+
+static xf80 from_ld(long double v) {
+    if (v == 0.0L) return xf_zero();
+    struct { uint64_t m; uint16_t se; } raw;
+    std::memset(&raw, 0, sizeof(raw));
+    std::memcpy(&raw, &v, 10);
+    xf80 r;
+    r.m = raw.m;
+    r.s = raw.se >> 15;
+    r.e = (int)(raw.se & 0x7FFF) - 16383;
+    return r;
+}
+static bool same(xf80 a, long double v) {
+    xf80 b = from_ld(v);
+    if (a.m == 0 && b.m == 0) return true;
+    return a.m == b.m && a.e == b.e && a.s == b.s;
+}
+
+int main(int argc, char** argv) {
+    long iters = argc > 1 ? atol(argv[1]) : 2000000;
+    int fails = 0;
+    {
+        xf80 c = from_ld(0.999L), e = from_ld(1e-8L);
+        printf("0.999L = {0x%016llXull, %d, %u}\n1e-8L = {0x%016llXull, %d, %u}\n",
+               (unsigned long long)c.m, c.e, c.s, (unsigned long long)e.m, e.e, e.s);
+        xf80 c2 = xf_const_0_999(), e2 = xf_const_1em8();
+        if (c.m != c2.m || c.e != c2.e || e.m != e2.m || e.e != e2.e) { printf("CONSTANT MISMATCH\n"); ++fails; }
+    }
+    std::mt19937_64 rng(12345);
+    auto rnd_ld = [&]() -> long double {
+        // random significand, moderate exponent spread, random sign; sometimes integers / near-equal values
+        uint64_t m = rng() | 0x8000000000000000ull;
+        int mode = rng() % 8;
+        if (mode == 0) m &= 0xFFFFFFFF00000000ull;
+        if (mode == 1) m &= 0xFFFFFFFFFFFFF800ull;
+        if (mode == 2) m = 0x8000000000000000ull;
+        int e = (int)(rng() % 140) - 70;
+        long double v = std::ldexp((long double)m, e - 63);
+        return (rng() & 1) ? -v : v;
+    };
+    for (long i = 0; i < iters && fails < 10; ++i) {
+        long double x = rnd_ld(), y = rnd_ld();
+        if (i % 5 == 0) y = x * (1.0L + std::ldexp((long double)((int)(rng() % 7) - 3), -(int)(rng() % 70)));
+        if (i % 11 == 0) y = std::ldexp(x, -(int)(rng() % 140));
+        if (y == 0.0L) y = 1.0L;
+        xf80 a = from_ld(x), b = from_ld(y);
+        volatile long double s = x + y, d = x - y, p = x * y, q = x / y;
+        if (!same(xf_add(a, b), s)) { printf("add fail %La %La\n", x, y); ++fails; }
+        if (!same(xf_sub(a, b), d)) { printf("sub fail %La %La\n", x, y); ++fails; }
+        if (!same(xf_mul(a, b), p)) { printf("mul fail %La %La\n", x, y); ++fails; }
+        if (!same(xf_div(a, b), q)) { printf("div fail %La %La\n", x, y); ++fails; }
+        if (xf_lt(a, b) != (x < y)) { printf("lt fail %La %La\n", x, y); ++fails; }
+        // q15
+        long double c = std::ldexp(x, -(int)(rng() % 80) + 2);
+        if (i % 3 == 0) {  // near half-integers in Q15
+            long double k = (long double)((int64_t)(rng() % 70000) - 35000) + 0.5L;
+            c = (k + std::ldexp((long double)((int)(rng() % 5) - 2), -(int)(rng() % 60))) / 32768.0L;
+        }
+        double dc = (double)c;
+        double sc = std::round(dc * 32768.0);
+        if (sc < -32768.0) sc = -32768.0;
+        if (sc > 32767.0) sc = 32767.0;
+        if (xf_to_q15(from_ld(c)) != (int16_t)sc) { printf("q15 fail %La -> %d vs %d\n", c, xf_to_q15(from_ld(c)), (int)sc); ++fails; }
+        // int conversion
+        int64_t iv = (int64_t)(rng() >> (rng() % 64)) * ((rng() & 1) ? 1 : -1);
+        if (!same(xf_from_i64(iv), (long double)iv)) { printf("i64 fail %lld\n", (long long)iv); ++fails; }
+    }
+    // Levinson vs oracle on synthetic autocorrelations of actual signals
+    std::mt19937 r2(777);
+    long lev_cases = 0;
+    for (int t = 0; t < 20000 && fails < 10; ++t) {
+        int n = 13 + (int)(r2() % 4000);
+        static int32_t x[5000];
+        int kind = t % 6;
+        double ph = 0, f = 0.001 + (r2() % 1000) / 2000.0;
+        int32_t amp = 1 << (1 + r2() % 23);
+        int32_t prev = 0;
+        for (int i = 0; i < n; ++i) {
+            int32_t v;
+            switch (kind) {
+                case 0: v = (int32_t)(r2() % (2 * amp)) - amp; break;
+                case 1: ph += f; v = (int32_t)(amp * std::sin(ph)); break;
+                case 2: prev = prev * 15 / 16 + ((int32_t)(r2() % 255) - 127); v = prev; break;
+                case 3: v = (i % 7 == 0) ? amp : 0; break;
+                case 4: v = (int32_t)(r2() % 3) - 1; break;
+                default: ph += f; v = (int32_t)(amp * std::sin(ph)) + (int32_t)(r2() % 17) - 8; break;
+            }
+            x[i] = v;
+        }
+        int64_t r[13];
+        laco_autocorr(x, (uint32_t)n, 12, r);
+        int16_t coef[5][13];
+        uint8_t used[5];
+        levinson_candidates(r, 12, coef, used);
+        for (int ci = 0; ci < 5; ++ci) {
+            int cand = 4 + 2 * ci;
+            int16_t oc[13];
+            int ou = laco_levinson_q15(r, cand, oc);
+            bool ok = ou == used[ci];
+            for (int j = 1; j <= cand && ok; ++j) ok = oc[j] == coef[ci][j];
+            if (!ok) { printf("levinson fail t=%d cand=%d used %d vs %d\n", t, cand, used[ci], ou); ++fails; }
+            ++lev_cases;
+        }
+    }
+    printf("x87 soft-float: %ld random op sets, %ld levinson solves, fails=%d\n", iters, lev_cases, fails);
+    return fails ? 1 : 0;
+}
