@@ -1,0 +1,149 @@
+/* lacx.h -- C ABI of the MI355X-native LAC block-encode path (liblacx.so).
+ *
+ * The reference (audexdev/Lossless-Audio-Codec, C++20) has no FFI layer: its encode boundary is two
+ * C++ classes.  Each entry point below names the reference interface it replaces; the C++ mirror
+ * classes with the reference's own signatures (lossless-audio-codec_amd/include/codec/...) are thin
+ * wrappers over this ABI, and INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ *   lacx_encode            <- LAC::Encoder::encode          ref src/codec/lac/encoder.hpp:22-24, encoder.cpp:215-466
+ *   lacx_encoder_create    <- LAC::Encoder::Encoder + set_zero_run_enabled / set_partitioning_enabled /
+ *                             set_thread_count               ref src/codec/lac/encoder.hpp:14-29
+ *   lacx_block_encode      <- Block::Encoder::encode        ref src/codec/block/encoder.hpp:15, encoder.cpp:313-838
+ *   lacx_analyze           <- the decisions inside Block::Encoder::encode / estimate_stereo_mode
+ *                                                            ref block/encoder.cpp:313-552, lac/encoder.cpp:126-197,321-373
+ *   lacx_emit_from_plans   <- the emit half of Block::Encoder::encode + container write
+ *                                                            ref block/encoder.cpp:554-838, lac/encoder.cpp:243-250,445-465
+ *   lacx_encode_shard /
+ *   lacx_assemble          <- the block loop + block table concat of LAC::Encoder::encode, split so that
+ *                             contiguous block ranges can be encoded by different GPUs/processes
+ *                                                            ref lac/encoder.cpp:252-263, 445-465
+ *
+ * All analysis runs in hand-written HIP kernels on a gfx950 device; there is no CPU fallback: every
+ * call that needs the device fails with LACX_E_DEVICE when none is usable.
+ */
+#ifndef LACX_H
+#define LACX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LACX_OK 0
+#define LACX_E_INVALID 1 /* maps to std::invalid_argument (ref lac/encoder.cpp:220-241) */
+#define LACX_E_RUNTIME 2 /* maps to std::runtime_error   (ref lac/encoder.cpp:447-449) */
+#define LACX_E_DEVICE 3  /* HIP failure / no device: std::runtime_error in the C++ mirror */
+
+#define LACX_MAX_BLOCK 16384u
+#define LACX_SLOTS_PER_BLOCK 16u /* slot = window*4 + channel(L,R,M,S); window 0 = whole block, 1..3 = probes */
+
+typedef struct lacx_encoder lacx_encoder;
+
+typedef struct lacx_config {
+    uint32_t sample_rate;         /* 44100 / 48000 / 96000 / 192000 */
+    uint8_t bit_depth;            /* 16 / 24 */
+    uint8_t stereo_mode;          /* 0 LR, 1 MS, 2 per-block auto (ignored for mono input) */
+    uint8_t zero_run_enabled;     /* reference default: 1 */
+    uint8_t partitioning_enabled; /* reference default: 1 */
+    int32_t device;               /* HIP device ordinal, -1 = current device */
+    uint32_t emit_threads;        /* host emit worker threads, 0 = hardware concurrency */
+} lacx_config;
+
+/* Same layout as lacx::ChannelPlan (csrc/lacx_types.h). */
+typedef struct lacx_channel_plan {
+    uint8_t predictor_type; /* 0 fixed, 1 FIR, 2 LPC */
+    uint8_t order;
+    uint8_t partition_order;
+    uint8_t valid;
+    int16_t coef[12];
+    uint32_t payload_bytes;
+    uint64_t total_bits;
+    uint8_t part_mode_k[256]; /* (mode << 5) | k */
+} lacx_channel_plan;
+
+/* Same layout as lacx::BlockPlan. */
+typedef struct lacx_block_plan {
+    uint8_t choose_ms;
+    uint8_t uncertain;
+    uint8_t est_ms;
+    uint8_t invalid;
+    uint32_t frames;
+    uint32_t first_bad;
+    uint32_t pad;
+} lacx_block_plan;
+
+typedef struct lacx_timing {
+    double h2d_ms;          /* host -> device PCM copy (0 for device-resident input) */
+    double analysis_ms;     /* all kernels, device timeline (hipEvent) */
+    double ingest_ms;       /* k_ingest + k_levinson */
+    double probe_ms;        /* k_analyze<4,64> + k_decide */
+    double full_ms;         /* k_analyze<16,1024> (the dominant kernel) */
+    double d2h_ms;          /* plan records device -> host, incl. stream sync */
+    double emit_ms;         /* host bit emit + container */
+    double total_ms;        /* wall time of the call */
+    uint64_t full_slots;    /* workgroups of the dominant kernel that did work */
+    uint64_t probe_slots;
+} lacx_timing;
+
+int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);
+void lacx_encoder_destroy(lacx_encoder* enc);
+const char* lacx_last_error(const lacx_encoder* enc);
+void lacx_free(void* p);
+void lacx_get_timing(const lacx_encoder* enc, lacx_timing* out);
+
+/* Whole-stream encode of host planar int32 PCM (right == NULL => mono). *out is malloc'd; free with
+ * lacx_free. Byte-identical to the reference's LAC::Encoder::encode output. */
+int lacx_encode(lacx_encoder* enc, const int32_t* left, const int32_t* right, uint64_t frames,
+                uint8_t** out, uint64_t* out_size);
+
+/* Same, with the PCM already resident in device memory (d_*), e.g. torch tensors.  h_left/h_right are
+ * the host copies the host-side emit reads; if NULL the library copies the PCM back itself.
+ * `stream` is a hipStream_t (NULL = the encoder's own stream). */
+int lacx_encode_device(lacx_encoder* enc, const int32_t* d_left, const int32_t* d_right,
+                       const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                       uint8_t** out, uint64_t* out_size);
+
+/* Device analysis only: fills bplans[nblocks] and plans[nblocks * LACX_SLOTS_PER_BLOCK]
+ * (nblocks = ceil(frames / 16384)). Host pointers in. */
+int lacx_analyze(lacx_encoder* enc, const int32_t* left, const int32_t* right, uint64_t frames,
+                 lacx_block_plan* bplans, lacx_channel_plan* plans);
+int lacx_analyze_device(lacx_encoder* enc, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                        void* stream, lacx_block_plan* bplans, lacx_channel_plan* plans);
+
+/* Host-only: emit + container from plans (no device needed). */
+int lacx_emit_from_plans(lacx_encoder* enc, const int32_t* left, const int32_t* right, uint64_t frames,
+                         const lacx_block_plan* bplans, const lacx_channel_plan* plans, uint8_t** out,
+                         uint64_t* out_size);
+
+/* Shard interface for multi-GPU block-range splits: encodes the blocks of a frame range that starts
+ * on a block boundary.  Returns the concatenated block payloads and a table of (frames, bytes) pairs
+ * (2 * nblocks uint32).  Both malloc'd. */
+int lacx_encode_shard(lacx_encoder* enc, const int32_t* left, const int32_t* right, uint64_t frames,
+                      uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks);
+int lacx_encode_shard_device(lacx_encoder* enc, const int32_t* d_left, const int32_t* d_right,
+                             const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                             uint8_t** payload, uint64_t* payload_size, uint32_t** table,
+                             uint32_t* nblocks);
+
+/* Host-only: header + block table + payload concat of shards given in stream order. */
+int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
+                  const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,
+                  uint8_t** out, uint64_t* out_size);
+
+/* Block::Encoder::encode drop-in for one channel block of n <= 16384 samples, |x| <= 2^24. */
+int lacx_block_encode(lacx_encoder* enc, const int32_t* pcm, uint32_t n, uint8_t** out, uint64_t* out_size);
+int lacx_block_plan_only(lacx_encoder* enc, const int32_t* pcm, uint32_t n, lacx_channel_plan* plan);
+
+/* Kernel-level probes for parity tests: exact autocorrelation + Q15 candidate sets of one channel
+ * block as the device computes them. acorr[13]; coef[5*13]; used[5]. */
+int lacx_debug_lpc(lacx_encoder* enc, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
+                   uint8_t* used);
+
+/* Number of visible HIP devices (0 when the runtime or a GPU is missing); does not initialise one. */
+int lacx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

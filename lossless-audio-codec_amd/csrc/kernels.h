@@ -1,0 +1,28 @@
+// kernels.h -- host-visible interface of kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "lacx_types.h"
+
+namespace lacx {
+
+// Device buffers sized for `num_blocks` blocks (allocated by the API layer).
+struct DeviceWorkspace {
+    ChannelPlan* plans = nullptr;   // [num_blocks][kSlotsPerBlock]
+    BlockPlan* bplans = nullptr;    // [num_blocks]
+    uint32_t* need_probe = nullptr; // [num_blocks] slot masks
+    uint32_t* need_full = nullptr;  // [num_blocks]
+    int64_t* acorr = nullptr;       // [num_blocks][kSlotsPerBlock][13]
+    LpcSet* lpcs = nullptr;         // [num_blocks][kSlotsPerBlock]
+};
+
+// Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).
+// ev: optional 5 events recorded at: start, after ingest+levinson, after probes+decide, after the
+// whole-block analysis kernel, end.
+hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
+                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev);
+
+size_t analyze_smem_bytes_full();
+size_t analyze_smem_bytes_probe();
+
+}  // namespace lacx

@@ -1,0 +1,644 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the LAC block-encode analysis path.
+//
+// Pipeline per shard of 16384-frame blocks (all launches asynchronous on one stream):
+//   k_ingest    one workgroup per block: sample-range validation, estimate_stereo_mode, exact 13-lag
+//               int64 autocorrelation for every slot (L,R,M,S x {whole block, 3 probe windows})
+//               -> BlockPlan, need masks, acorr[]          (ref lac/encoder.cpp:82-102,126-197; lpc.cpp:80-96)
+//   k_levinson  one lane per slot: Levinson-Durbin in software x87 extended precision -> Q15 sets
+//                                                           (ref lpc.cpp:98-186)
+//   k_analyze<4,64>     one wave per probe slot of an "uncertain" block (ref lac/encoder.cpp:341-354)
+//   k_decide(1) probes -> LR/MS choice, marks the two whole-block slots still to be analysed
+//   k_analyze<16,1024>  one 1024-thread workgroup per needed whole-block slot
+//                                                           (ref block/encoder.cpp:313-552)
+//   k_decide(2) small-block full comparison (ref lac/encoder.cpp:336-340), final BlockPlan
+// The bit-serial emit stays on the host (emit.cpp), driven by the ChannelPlan records.
+#include <hip/hip_runtime.h>
+
+#include "analyze_core.h"
+#include "kernels.h"
+
+namespace lacx {
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
+    const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, d, 64);
+    const uint32_t hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {  // result valid in lane 0
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_down((int)v, d, 64);
+    return v;
+}
+
+// Block exclusive scans of the per-thread values the phases left in tabP/tabNZ (sum / max).
+// part 1 before the barrier, part 2 after it.
+template <class G>
+struct ScanRegs {
+    uint64_t v, inc;
+    int32_t z, zinc;
+};
+
+template <class G>
+__device__ __forceinline__ void scan_pz_part1(Smem<G>& sh, int tid, ScanRegs<G>& r) {
+    const int lane = tid & 63, wave = tid >> 6;
+    r.v = sh.tabP[tid];
+    r.z = sh.tabNZ[tid];
+    uint64_t inc = r.v;
+    int32_t zinc = r.z;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = shfl_up_u64(inc, d);
+        const int32_t oz = __shfl_up(zinc, d, 64);
+        if (lane >= d) {
+            inc += o;
+            zinc = oz > zinc ? oz : zinc;
+        }
+    }
+    r.inc = inc;
+    r.zinc = zinc;
+    if (lane == 63) {
+        sh.wtotP[wave] = inc;
+        sh.wtotZ[wave] = zinc;
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void scan_pz_part2(Smem<G>& sh, int tid, const ScanRegs<G>& r) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint64_t base = 0;
+    int32_t zbase = -1;
+    for (int w = 0; w < wave; ++w) {
+        base += sh.wtotP[w];
+        const int32_t z = sh.wtotZ[w];
+        zbase = z > zbase ? z : zbase;
+    }
+    int32_t zprev = __shfl_up(r.zinc, 1, 64);
+    if (lane == 0) zprev = -1;
+    sh.tabP[tid] = base + r.inc - r.v;
+    sh.tabNZ[tid] = zprev > zbase ? zprev : zbase;
+    if (tid == G::T - 1) {
+        sh.tabP[G::T] = base + r.inc;
+        sh.tabNZ[G::T] = r.zinc > zbase ? r.zinc : zbase;
+    }
+}
+
+template <class G>
+__device__ __forceinline__ uint32_t scan_f_part1(Smem<G>& sh, int tid, uint32_t& own) {
+    const int lane = tid & 63, wave = tid >> 6;
+    own = sh.tabF[tid];
+    uint32_t inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) sh.wtotF[wave] = inc;
+    return inc;
+}
+
+template <class G>
+__device__ __forceinline__ void scan_f_part2(Smem<G>& sh, int tid, uint32_t inc, uint32_t own) {
+    const int wave = tid >> 6;
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += sh.wtotF[w];
+    sh.tabF[tid] = base + inc - own;
+    if (tid == G::T - 1) sh.tabF[G::T] = base + inc;
+}
+
+// Per-plane population counts of the wave's bit-sliced chunk counters, via ballots; lanes 0..29 then
+// add their plane's count to the block totals.
+template <class G>
+__device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t* planeTot, uint32_t* planeTot256,
+                                                  int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t mine = 0, mine256 = 0;
+    // lanes of wave 0 whose chunk lies inside the first 256 samples
+    const uint64_t m256 = (G::W256 >= 64) ? ~0ull : ((1ull << (G::W256 & 63)) - 1ull);
+#pragma unroll
+    for (int l = 0; l < G::LV; ++l) {
+        const uint32_t c = th.cs[l];
+        for (int b = 0; b < 30; ++b) {
+            const uint64_t m = __ballot((c >> b) & 1u);
+            const uint32_t cnt = (uint32_t)__popcll(m) << l;
+            const uint32_t cnt256 = (uint32_t)__popcll(m & m256) << l;
+            if (lane == b) {
+                mine += cnt;
+                mine256 += cnt256;
+            }
+        }
+    }
+    if (lane < 30) {
+        atomicAdd(&planeTot[lane], mine);
+        if (wave == 0) atomicAdd(&planeTot256[lane], mine256);
+    }
+}
+
+// Exclusive scan of an LDS array by one wave (row of 64 at a time, running carry).
+__device__ __forceinline__ void wave_exclusive_scan_u32(uint32_t* arr, int len, int lane) {
+    uint32_t carry = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int i = base + lane;
+        const uint32_t v = (i < len) ? arr[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (i < len) arr[i] = carry + inc - v;
+        carry += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// slot geometry
+// ---------------------------------------------------------------------------------------------
+struct SlotGeom {
+    int64_t start;  // first frame (shard-relative)
+    uint32_t n;     // frames in the slot
+    bool defined;
+};
+
+__device__ __forceinline__ uint32_t block_frames(const AnalyzeParams& prm, uint32_t blk) {
+    const uint64_t rem = prm.frames - (uint64_t)blk * kMaxBlock;
+    return rem < (uint64_t)kMaxBlock ? (uint32_t)rem : (uint32_t)kMaxBlock;
+}
+
+__device__ __forceinline__ SlotGeom slot_geom(const AnalyzeParams& prm, uint32_t blk, int slot) {
+    SlotGeom g;
+    const uint32_t nb = block_frames(prm, blk);
+    const int64_t bstart = (int64_t)blk * kMaxBlock;
+    const int win = slot >> 2, ch = slot & 3;
+    g.defined = true;
+    if (prm.channels == 1 && ch != 0) g.defined = false;
+    if (win == 0) {
+        g.start = bstart;
+        g.n = nb;
+    } else {
+        // probe windows exist only for per-block stereo on blocks above the full-comparison limit
+        if (prm.channels != 2 || prm.stereo_mode != 2 || nb <= (uint32_t)kFullCompareLimit) g.defined = false;
+        g.n = kProbe;
+        g.start = bstart;
+        if (g.defined) {
+            if (win == 2) g.start = bstart + (nb - kProbe) / 2u;
+            if (win == 3) g.start = bstart + nb - kProbe;
+        }
+    }
+    return g;
+}
+
+__device__ __forceinline__ SlotSrc slot_src(const int32_t* L, const int32_t* R, int ch) {
+    SlotSrc s;
+    s.kind = ch;
+    if (ch == CH_R) {
+        s.a = R;
+        s.b = nullptr;
+    } else {
+        s.a = L;
+        s.b = R;
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ingest
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t zz64(int64_t v) {  // ref lac/encoder.cpp:38-41
+    return v >= 0 ? ((uint64_t)v << 1) : ((((uint64_t)(-(v + 1))) << 1) | 1u);
+}
+
+__device__ __forceinline__ uint64_t approx_rice_bits(uint64_t sum, uint64_t count) {  // ref lac/encoder.cpp:43-57
+    if (count == 0) return 0;
+    const uint64_t mean = (sum + (count >> 1)) / count;
+    uint32_t k = 0;
+    while (k < 31u && ((uint64_t)1 << k) < mean) ++k;
+    return (sum >> k) + count * (uint64_t)(k + 1u);  // saturation is unreachable for <= 2^14 samples of <= 2^27
+}
+
+constexpr int kIngestThreads = 256;
+
+__global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __restrict__ L,
+                                                           const int32_t* __restrict__ R, AnalyzeParams prm,
+                                                           BlockPlan* __restrict__ bplans,
+                                                           uint32_t* __restrict__ need_probe,
+                                                           uint32_t* __restrict__ need_full,
+                                                           int64_t* __restrict__ acorr) {
+    __shared__ unsigned long long s_sums[12];
+    __shared__ unsigned long long s_ac[13];
+    __shared__ unsigned int s_bad;
+    const uint32_t blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nb = block_frames(prm, blk);
+    const int64_t bstart = (int64_t)blk * kMaxBlock;
+    const bool stereo = prm.channels == 2;
+    if (tid < 12) s_sums[tid] = 0;
+    if (tid == 0) s_bad = 0xFFFFFFFFu;
+    __syncthreads();
+
+    // pass 1: range validation (+ the 12 proxy sums of estimate_stereo_mode for per-block stereo)
+    {
+        const int32_t lo = prm.bit_depth == 16 ? -32768 : (prm.bit_depth == 24 ? -0x800000 : INT32_MIN);
+        const int32_t hi = prm.bit_depth == 16 ? 32767 : (prm.bit_depth == 24 ? 0x7FFFFF : INT32_MAX);
+        uint64_t sums[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sums[i] = 0;
+        uint32_t bad = 0xFFFFFFFFu;
+        const bool est = stereo && prm.stereo_mode == 2;
+        for (uint32_t i = tid; i < nb; i += kIngestThreads) {
+            const int64_t l = L[bstart + i];
+            const int64_t r = stereo ? R[bstart + i] : 0;
+            if (l < lo || l > hi) bad = bad < i ? bad : i;
+            if (stereo && (r < lo || r > hi)) bad = bad < (i | 0x80000000u) ? bad : (i | 0x80000000u);
+            if (est) {
+                const int64_t m = (l + r) >> 1, s = l - r;
+                int64_t pl = 0, pr = 0, pm = 0, ps = 0;
+                if (i > 0) {
+                    pl = L[bstart + i - 1];
+                    pr = R[bstart + i - 1];
+                    pm = (pl + pr) >> 1;
+                    ps = pl - pr;
+                }
+                const int64_t cur[4] = {l, r, m, s};
+                const int64_t prev[4] = {pl, pr, pm, ps};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint64_t raw = zz64(cur[c]);
+                    sums[c] += raw;
+                    sums[4 + c] += (i == 0) ? raw : zz64(cur[c] - prev[c]);
+                    sums[8 + c] += (i == 0) ? raw : zz64(cur[c] + prev[c]);
+                }
+            }
+        }
+        if (est) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const uint64_t t = wave_sum_u64(sums[i]);
+                if (lane == 0) atomicAdd(&s_sums[i], (unsigned long long)t);
+            }
+        }
+        // first bad sample: left channel wins over right at the same index (left is validated first)
+        if (bad != 0xFFFFFFFFu) atomicMin(&s_bad, bad);
+    }
+
+    // pass 2: autocorrelation of every defined slot
+    for (int slot = 0; slot < kSlotsPerBlock; ++slot) {
+        const SlotGeom g = slot_geom(prm, blk, slot);
+        if (!g.defined) continue;  // uniform
+        if (slot >= 4 && !(stereo && prm.stereo_mode == 2)) continue;
+        const int ch = slot & 3;
+        if (slot < 4 && stereo) {
+            if (prm.stereo_mode == 0 && ch >= 2) continue;
+            if (prm.stereo_mode == 1 && ch < 2) continue;
+        }
+        if (tid < 13) s_ac[tid] = 0;
+        __syncthreads();
+        const SlotSrc src = slot_src(L, R, ch);
+        int64_t acc[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) acc[k] = 0;
+        for (uint32_t i = tid; i < g.n; i += kIngestThreads) {
+            const int64_t x0 = slot_fetch(src, g.start + i);
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                if (i >= (uint32_t)k) acc[k] += x0 * (int64_t)slot_fetch(src, g.start + i - k);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            const uint64_t t = wave_sum_u64((uint64_t)acc[k]);
+            if (lane == 0) atomicAdd(&s_ac[k], (unsigned long long)t);
+        }
+        __syncthreads();
+        if (tid < 13) acorr[((size_t)blk * kSlotsPerBlock + slot) * 13 + tid] = (int64_t)s_ac[tid];
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        BlockPlan bp;
+        bp.choose_ms = 0;
+        bp.uncertain = 0;
+        bp.est_ms = 0;
+        bp.invalid = s_bad != 0xFFFFFFFFu;
+        bp.frames = nb;
+        bp.first_bad = s_bad;
+        bp.pad = 0;
+        uint32_t nprobe = 0, nfull = 0;
+        if (!stereo) {
+            nfull = 1u;
+        } else if (prm.stereo_mode == 0) {
+            nfull = 0x3u;
+        } else if (prm.stereo_mode == 1) {
+            nfull = 0xCu;
+            bp.choose_ms = 1;
+        } else {
+            // estimate_channel_proxy_cost + decision: ref lac/encoder.cpp:114-124, 179-196
+            uint64_t bits[4];
+            bool active = false;
+            for (int c = 0; c < 4; ++c) {
+                const uint64_t raw = approx_rice_bits(s_sums[c], nb);
+                const uint64_t dif = approx_rice_bits(s_sums[4 + c], nb);
+                const uint64_t ant = approx_rice_bits(s_sums[8 + c], nb);
+                uint64_t mn = raw < dif ? raw : dif;
+                if (ant < mn) mn = ant;
+                bits[c] = mn;
+                active = active || (raw < dif) || (ant < dif);
+            }
+            const uint64_t lr = bits[0] + bits[1], ms = bits[2] + bits[3];
+            const uint64_t smaller = lr < ms ? lr : ms;
+            const uint64_t diff = lr >= ms ? lr - ms : ms - lr;
+            bp.est_ms = ms < lr;
+            bp.choose_ms = bp.est_ms;
+            bp.uncertain = smaller == 0 || diff == 0 || active || diff <= smaller / 100u;
+            if (!bp.uncertain) {
+                nfull = bp.est_ms ? 0xCu : 0x3u;
+            } else if (nb <= (uint32_t)kFullCompareLimit) {
+                nfull = 0xFu;  // encode both, compare sizes (k_decide phase 2)
+            } else {
+                nprobe = 0xFFF0u;  // 12 probe slots; the whole-block pair is picked by k_decide phase 1
+            }
+        }
+        bplans[blk] = bp;
+        need_probe[blk] = nprobe;
+        need_full[blk] = nfull;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_levinson: one lane per slot
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_levinson(AnalyzeParams prm, const int64_t* __restrict__ acorr,
+                                                 LpcSet* __restrict__ lpcs) {
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t blk = gid / kSlotsPerBlock;
+    const int slot = (int)(gid % kSlotsPerBlock);
+    if (blk >= prm.num_blocks) return;
+    const SlotGeom g = slot_geom(prm, blk, slot);
+    if (!g.defined) return;
+    if (prm.channels == 2 && slot < 4) {
+        if (prm.stereo_mode == 0 && (slot & 3) >= 2) return;
+        if (prm.stereo_mode == 1 && (slot & 3) < 2) return;
+    }
+    int64_t r[13];
+    for (int k = 0; k < 13; ++k) r[k] = acorr[(size_t)gid * 13 + k];
+    const int mvo = (g.n > 1) ? (int)((g.n - 1 < 32u) ? g.n - 1 : 32u) : 0;
+    LpcSet out;
+    levinson_candidates(r, mvo, out.coef, out.used);
+    out.pad = 0;
+    lpcs[gid] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_analyze
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
+                                                  AnalyzeParams prm, int probe_class,
+                                                  const LpcSet* __restrict__ lpcs,
+                                                  const uint32_t* __restrict__ need,
+                                                  ChannelPlan* __restrict__ plans) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
+    const int tid = threadIdx.x;
+    uint32_t blk;
+    int slot;
+    if (probe_class) {
+        blk = blockIdx.x / 12u;
+        slot = 4 + (int)(blockIdx.x % 12u);
+    } else {
+        const uint32_t per = prm.channels == 2 ? 4u : 1u;
+        blk = blockIdx.x / per;
+        slot = (int)(blockIdx.x % per);
+    }
+    if (!((need[blk] >> slot) & 1u)) return;  // uniform for the workgroup
+    const SlotGeom g = slot_geom(prm, blk, slot);
+    const uint32_t n = g.n;
+    const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
+    const SlotSrc src = slot_src(L, R, slot & 3);
+
+    Thread<G> th;
+    load_chunk(th, src, g.start, n, tid);
+    for (int i = tid; i < (int)(sizeof(LpcSet) / 2); i += G::T)
+        reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(&lpcs[sidx])[i];
+    if (tid < 32) {
+        sh.planeTot[0][tid] = sh.planeTot[1][tid] = 0;
+        sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
+    }
+    if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
+    if (tid == 0) sh.best_cand = -1;
+    __syncthreads();
+
+    int pending = -1;        // candidate whose totals thread 0 still has to score
+    uint32_t pending_k0 = 0;
+    int parity = 0;
+    for (int cand = 0; cand <= 10; ++cand) {
+        if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
+        uint32_t* pt = sh.planeTot[parity];
+        uint32_t* pt256 = sh.planeTot256[parity];
+        unsigned long long* acc = sh.acc[parity];
+        if (tid == 0 && pending >= 0) {
+            // previous candidate's totals sit in the other buffers: score it, then clear them
+            score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
+            for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
+            for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
+        }
+        residual_chunk(th, cand, sh.lpc);
+        phase_r(th, sh);
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        plane_totals_wave(th, pt, pt256, tid);
+        __syncthreads();  // B1
+        scan_pz_part2(sh, tid, sr);
+        if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
+        __syncthreads();  // B2
+        phase_a(th, sh);
+        uint32_t fown;
+        const uint32_t finc = scan_f_part1(sh, tid, fown);
+        __syncthreads();  // B3
+        scan_f_part2(sh, tid, finc, fown);
+        __syncthreads();  // B4
+        const uint32_t k0 = sh.cur_k0;
+        phase_b(th, sh, k0);
+        {
+            const bool active = (uint32_t)th.a < n;
+            const uint64_t r0 = wave_sum_u64(active ? th.crice : 0ull);
+            const uint64_t r1 = wave_sum_u64(active ? th.cbin : 0ull);
+            const uint64_t r2 = wave_sum_u64(active ? th.czr : 0ull);
+            const uint32_t r3 = wave_or_u32(active ? th.chasrun : 0u);
+            if ((tid & 63) == 0) {
+                atomicAdd(&acc[0], (unsigned long long)r0);
+                atomicAdd(&acc[1], (unsigned long long)r1);
+                atomicAdd(&acc[2], (unsigned long long)r2);
+                atomicAdd(&acc[3], (unsigned long long)r3);
+            }
+        }
+        __syncthreads();  // B5
+        pending = cand;
+        pending_k0 = k0;
+        parity ^= 1;
+    }
+    if (tid == 0) score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
+    __syncthreads();
+
+    // ---- partition search on the winning residual -------------------------------------------
+    const int best = sh.best_cand;
+    residual_chunk(th, best, sh.lpc);
+    phase_r(th, sh);
+    store_u_plain(th, sh);
+    int max_p = 0;
+    if (prm.partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
+    const int nseg = max_p > 0 ? ((2 << max_p) - 2) : 0;
+    for (int i = tid; i < 15 * (G::NG + 1); i += G::T) (&sh.grp[0][0])[i] = 0;
+    for (int i = tid; i < nseg; i += G::T) {
+        sh.segacc[i][0] = sh.segacc[i][1] = sh.segacc[i][2] = 0;
+        sh.segrun[i] = 0;
+    }
+    if (tid <= G::MAXP) sh.pbits[tid] = 0;
+    {
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        __syncthreads();
+        scan_pz_part2(sh, tid, sr);
+        __syncthreads();
+    }
+    if (max_p > 0) {
+        {
+            uint32_t words[15];
+            packed_planes(th, words);
+#pragma unroll
+            for (int w = 0; w < 15; ++w) atomicAdd(&sh.grp[w][tid / G::TPG], words[w]);
+        }
+        __syncthreads();
+        {
+            constexpr int NW = G::T / 64;
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(sh.grp[w], G::NG + 1, lane);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nseg; idx += G::T) {
+            const int p = 31 - __clz(idx + 2);
+            seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
+        }
+        __syncthreads();
+        for (int p = 1; p <= max_p; ++p) {
+            partition_pass(th, sh, p,
+                           [&sh](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
+                                 uint32_t hr) {
+                               atomicAdd(&sh.segacc[idx][0], rc);
+                               atomicAdd(&sh.segacc[idx][1], bn);
+                               atomicAdd(&sh.segacc[idx][2], zr);
+                               if (hr) atomicOr(&sh.segrun[idx], 1u);
+                           });
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nseg; idx += G::T) {
+            const int p = 31 - __clz(idx + 2);
+            const unsigned long long bits = seg_choose(sh, (uint32_t)idx, prm.zero_run);
+            atomicAdd(&sh.pbits[p], bits);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &plans[sidx]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_decide
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, BlockPlan* __restrict__ bplans,
+                                               const uint32_t* __restrict__ need_probe,
+                                               uint32_t* __restrict__ need_full,
+                                               const ChannelPlan* __restrict__ plans) {
+    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= prm.num_blocks) return;
+    if (prm.channels != 2 || prm.stereo_mode != 2) return;
+    BlockPlan bp = bplans[blk];
+    if (!bp.uncertain) return;
+    const ChannelPlan* p = plans + (size_t)blk * kSlotsPerBlock;
+    if (phase == 1) {
+        if (need_probe[blk] == 0) return;
+        uint64_t lr = 0, ms = 0;  // ref lac/encoder.cpp:347-353
+        for (int w = 1; w <= 3; ++w) {
+            lr += (uint64_t)p[w * 4 + CH_L].payload_bytes + p[w * 4 + CH_R].payload_bytes;
+            ms += (uint64_t)p[w * 4 + CH_M].payload_bytes + p[w * 4 + CH_S].payload_bytes;
+        }
+        bp.choose_ms = ms < lr;
+        bplans[blk] = bp;
+        need_full[blk] = bp.choose_ms ? 0xCu : 0x3u;
+    } else {
+        if (bp.frames > (uint32_t)kFullCompareLimit) return;
+        const uint64_t lr = (uint64_t)p[CH_L].payload_bytes + p[CH_R].payload_bytes;  // ref lac/encoder.cpp:337-339
+        const uint64_t ms = (uint64_t)p[CH_M].payload_bytes + p[CH_S].payload_bytes;
+        bp.choose_ms = ms < lr;
+        bplans[blk] = bp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------------------------
+using GFull = Geo<16, 1024>;
+using GProbe = Geo<4, 64>;
+
+size_t analyze_smem_bytes_full() { return sizeof(Smem<GFull>); }
+size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
+
+static hipError_t set_smem_attr() {
+    static hipError_t cached = hipErrorUnknown;
+    static bool done = false;
+    if (!done) {
+        cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GFull>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GFull>));
+        if (cached == hipSuccess)
+            cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
+        done = true;
+    }
+    return cached;
+}
+
+hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
+                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev) {
+    hipError_t e = set_smem_attr();
+    if (e != hipSuccess) return e;
+    const uint32_t nb = prm.num_blocks;
+    if (nb == 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ingest, dim3(nb), dim3(kIngestThreads), 0, stream, d_left, d_right, prm, ws.bplans,
+                       ws.need_probe, ws.need_full, ws.acorr);
+    hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + 63) / 64), dim3(64), 0, stream, prm, ws.acorr,
+                       ws.lpcs);
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
+    if (autost) {
+        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
+                           d_right, prm, 1, ws.lpcs, ws.need_probe, ws.plans);
+        hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
+                           ws.need_full, ws.plans);
+    }
+    if (ev) (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * (prm.channels == 2 ? 4u : 1u)), dim3(GFull::T),
+                       sizeof(Smem<GFull>), stream, d_left, d_right, prm, 0, ws.lpcs, ws.need_full, ws.plans);
+    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (autost) {
+        hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,
+                           ws.need_full, ws.plans);
+    }
+    if (ev) (void)hipEventRecord(ev[4], stream);
+    return hipGetLastError();
+}
+
+}  // namespace lacx

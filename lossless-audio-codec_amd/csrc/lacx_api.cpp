@@ -1,0 +1,588 @@
+// lacx_api.cpp -- implementation of the C ABI declared in include/lacx.h.
+//
+// Thin host layer: owns the HIP stream, the device workspace and pinned plan buffers, enqueues the
+// kernels (kernels.hip), and runs the host emit (emit.cpp) from the returned plan records.
+// There is no CPU analysis path here: without a usable HIP device every analysing call fails.
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "emit.h"
+#include "kernels.h"
+#include "lacx.h"
+
+using namespace lacx;
+
+static_assert(sizeof(lacx_channel_plan) == sizeof(ChannelPlan), "ABI plan layout");
+static_assert(sizeof(lacx_block_plan) == sizeof(BlockPlan), "ABI block plan layout");
+static_assert(sizeof(ChannelPlan) == 296, "ChannelPlan layout");
+
+struct lacx_encoder {
+    lacx_config cfg{};
+    bool device_ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};
+    DeviceWorkspace ws{};
+    uint32_t ws_blocks = 0;
+    int32_t* d_left = nullptr;
+    int32_t* d_right = nullptr;
+    uint64_t d_cap = 0;
+    ChannelPlan* h_plans = nullptr;  // pinned
+    BlockPlan* h_bplans = nullptr;   // pinned
+    uint32_t h_blocks = 0;
+    std::string err;
+    lacx_timing timing{};
+};
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+int fail(lacx_encoder* e, int code, const std::string& msg) {
+    if (e) e->err = msg;
+    return code;
+}
+
+int hip_fail(lacx_encoder* e, hipError_t err, const char* what) {
+    return fail(e, LACX_E_DEVICE, std::string(what) + ": " + hipGetErrorString(err));
+}
+
+#define HIP_TRY(e, call, what)                          \
+    do {                                                \
+        const hipError_t _err = (call);                 \
+        if (_err != hipSuccess) return hip_fail(e, _err, what); \
+    } while (0)
+
+int ensure_device(lacx_encoder* e) {
+    if (e->device_ready) return LACX_OK;
+    int count = 0;
+    const hipError_t ce = hipGetDeviceCount(&count);
+    if (ce != hipSuccess || count <= 0)
+        return fail(e, LACX_E_DEVICE, "no HIP device available: the LAC analysis path has no CPU fallback");
+    int dev = e->cfg.device;
+    if (dev < 0) HIP_TRY(e, hipGetDevice(&dev), "hipGetDevice");
+    if (dev >= count) return fail(e, LACX_E_DEVICE, "HIP device ordinal out of range");
+    HIP_TRY(e, hipSetDevice(dev), "hipSetDevice");
+    e->device = dev;
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto& ev : e->ev) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
+    e->device_ready = true;
+    return LACX_OK;
+}
+
+void free_workspace(lacx_encoder* e) {
+    if (e->ws.plans) (void)hipFree(e->ws.plans);
+    if (e->ws.bplans) (void)hipFree(e->ws.bplans);
+    if (e->ws.need_probe) (void)hipFree(e->ws.need_probe);
+    if (e->ws.need_full) (void)hipFree(e->ws.need_full);
+    if (e->ws.acorr) (void)hipFree(e->ws.acorr);
+    if (e->ws.lpcs) (void)hipFree(e->ws.lpcs);
+    e->ws = DeviceWorkspace{};
+    e->ws_blocks = 0;
+}
+
+int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
+    if (nblocks > e->ws_blocks) {
+        free_workspace(e);
+        const size_t slots = (size_t)nblocks * kSlotsPerBlock;
+        HIP_TRY(e, hipMalloc((void**)&e->ws.plans, slots * sizeof(ChannelPlan)), "hipMalloc(plans)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.bplans, (size_t)nblocks * sizeof(BlockPlan)), "hipMalloc(bplans)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.need_probe, (size_t)nblocks * 4), "hipMalloc(need)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.need_full, (size_t)nblocks * 4), "hipMalloc(need)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.acorr, slots * 13 * sizeof(int64_t)), "hipMalloc(acorr)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.lpcs, slots * sizeof(LpcSet)), "hipMalloc(lpcs)");
+        e->ws_blocks = nblocks;
+    }
+    if (nblocks > e->h_blocks) {
+        if (e->h_plans) (void)hipHostFree(e->h_plans);
+        if (e->h_bplans) (void)hipHostFree(e->h_bplans);
+        e->h_plans = nullptr;
+        e->h_bplans = nullptr;
+        e->h_blocks = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_plans, (size_t)nblocks * kSlotsPerBlock * sizeof(ChannelPlan), 0),
+                "hipHostMalloc(plans)");
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_bplans, (size_t)nblocks * sizeof(BlockPlan), 0),
+                "hipHostMalloc(bplans)");
+        e->h_blocks = nblocks;
+    }
+    return LACX_OK;
+}
+
+int ensure_pcm(lacx_encoder* e, uint64_t frames, bool stereo) {
+    if (frames > e->d_cap || (stereo && !e->d_right)) {
+        if (e->d_left) (void)hipFree(e->d_left);
+        if (e->d_right) (void)hipFree(e->d_right);
+        e->d_left = e->d_right = nullptr;
+        e->d_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_left, frames * sizeof(int32_t)), "hipMalloc(left)");
+        HIP_TRY(e, hipMalloc((void**)&e->d_right, frames * sizeof(int32_t)), "hipMalloc(right)");
+        e->d_cap = frames;
+    }
+    return LACX_OK;
+}
+
+bool rate_ok(uint32_t sr) { return sr == 44100 || sr == 48000 || sr == 96000 || sr == 192000; }
+
+// Argument validation of LAC::Encoder::encode (ref lac/encoder.cpp:220-237), same order and wording.
+int validate_stream_args(lacx_encoder* e, const void* left, uint64_t frames) {
+    if (left == nullptr || frames == 0) return fail(e, LACX_E_INVALID, "left channel must not be empty");
+    if (!rate_ok(e->cfg.sample_rate))
+        return fail(e, LACX_E_INVALID, "unsupported sample rate: " + std::to_string(e->cfg.sample_rate));
+    if (!(e->cfg.bit_depth == 16 || e->cfg.bit_depth == 24))
+        return fail(e, LACX_E_INVALID, "unsupported bit depth: " + std::to_string((int)e->cfg.bit_depth));
+    if (e->cfg.stereo_mode > 2)
+        return fail(e, LACX_E_INVALID, "unsupported stereo mode: " + std::to_string((int)e->cfg.stereo_mode));
+    return LACX_OK;
+}
+
+uint32_t blocks_for(uint64_t frames) { return (uint32_t)((frames + kMaxBlock - 1) / kMaxBlock); }
+
+// Runs the kernels on device-resident PCM; leaves plans in the pinned host buffers.
+int analyze_on_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                      int channels, int stereo_mode, int bit_depth, hipStream_t stream) {
+    const uint32_t nb = blocks_for(frames);
+    int rc = ensure_workspace(e, nb);
+    if (rc) return rc;
+    AnalyzeParams prm{};
+    prm.frames = frames;
+    prm.num_blocks = nb;
+    prm.first_block = 0;
+    prm.channels = channels;
+    prm.stereo_mode = channels == 2 ? stereo_mode : 0;
+    prm.bit_depth = bit_depth;
+    prm.zero_run = e->cfg.zero_run_enabled ? 1 : 0;
+    prm.partitioning = e->cfg.partitioning_enabled ? 1 : 0;
+    HIP_TRY(e, launch_analysis(d_left, d_right, prm, e->ws, stream, e->ev), "kernel launch");
+    const auto t0 = clk::now();
+    HIP_TRY(e, hipMemcpyAsync(e->h_plans, e->ws.plans, (size_t)nb * kSlotsPerBlock * sizeof(ChannelPlan),
+                              hipMemcpyDeviceToHost, stream),
+            "D2H plans");
+    HIP_TRY(e, hipMemcpyAsync(e->h_bplans, e->ws.bplans, (size_t)nb * sizeof(BlockPlan), hipMemcpyDeviceToHost,
+                              stream),
+            "D2H block plans");
+    HIP_TRY(e, hipStreamSynchronize(stream), "stream synchronize");
+    e->timing.d2h_ms = ms_since(t0);  // includes waiting for the kernels when called back to back
+    float f = 0;
+    (void)hipEventElapsedTime(&f, e->ev[0], e->ev[4]);
+    e->timing.analysis_ms = f;
+    (void)hipEventElapsedTime(&f, e->ev[0], e->ev[1]);
+    e->timing.ingest_ms = f;
+    (void)hipEventElapsedTime(&f, e->ev[1], e->ev[2]);
+    e->timing.probe_ms = f;
+    (void)hipEventElapsedTime(&f, e->ev[2], e->ev[3]);
+    e->timing.full_ms = f;
+    uint64_t fs = 0, ps = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const ChannelPlan* s = e->h_plans + (size_t)b * kSlotsPerBlock;
+        for (int i = 0; i < 4; ++i) fs += s[i].valid;
+        for (int i = 4; i < kSlotsPerBlock; ++i) ps += s[i].valid;
+    }
+    e->timing.full_slots = fs;
+    e->timing.probe_slots = ps;
+    return LACX_OK;
+}
+
+// Sample-range errors in the reference's order: all of left first, then right (ref lac/encoder.cpp:238-241).
+int check_sample_range(lacx_encoder* e, uint32_t nb) {
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t b = 0; b < nb; ++b) {
+            const BlockPlan& bp = e->h_bplans[b];
+            if (!bp.invalid) continue;
+            const bool is_right = (bp.first_bad >> 31) != 0;
+            if ((pass == 0) != !is_right) {
+                // a block whose first bad sample is on the right may still hide a left one only if the
+                // left channel of that block is clean (left wins the per-block minimum), so this is exact
+                continue;
+            }
+            const uint64_t idx = (uint64_t)b * kMaxBlock + (bp.first_bad & 0x7FFFFFFFu);
+            return fail(e, LACX_E_INVALID,
+                        std::string(is_right ? "right" : "left") + " sample at index " + std::to_string(idx) +
+                            " is outside the configured PCM bit depth");
+        }
+    }
+    return LACX_OK;
+}
+
+struct ShardOut {
+    std::vector<uint64_t> offsets;
+    uint64_t payload_size = 0;
+};
+
+void layout_payload(const StreamParams& sp, const BlockPlan* bp, const ChannelPlan* plans, uint32_t nb,
+                    ShardOut& so) {
+    so.offsets.resize(nb);
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        so.offsets[b] = off;
+        off += block_payload_bytes(sp, bp[b], plans + (size_t)b * kSlotsPerBlock);
+    }
+    so.payload_size = off;
+}
+
+StreamParams stream_params(const lacx_config& c, int channels) {
+    StreamParams sp;
+    sp.sample_rate = c.sample_rate;
+    sp.bit_depth = c.bit_depth;
+    sp.channels = (uint8_t)channels;
+    sp.stereo_mode = channels == 2 ? c.stereo_mode : 0;
+    return sp;
+}
+
+void put32(uint8_t* p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+// header + block table + payloads from host plans (ref lac/encoder.cpp:243-250, 445-465)
+int emit_stream(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
+                const BlockPlan* bplans, const ChannelPlan* plans, uint8_t** out, uint64_t* out_size) {
+    const auto t0 = clk::now();
+    const int channels = right ? 2 : 1;
+    const uint32_t nb = blocks_for(frames);
+    const StreamParams sp = stream_params(e->cfg, channels);
+    ShardOut so;
+    layout_payload(sp, bplans, plans, nb, so);
+    const uint64_t head = 10 + 4 + 8ull * nb;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + so.payload_size));
+    if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
+    write_frame_header(sp, buf);
+    put32(buf + 10, nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t size = ((b + 1 < nb) ? so.offsets[b + 1] : so.payload_size) - so.offsets[b];
+        if (size == 0 || size > 0xFFFFFFFFull) {
+            std::free(buf);
+            return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+        }
+        put32(buf + 14 + 8ull * b, bplans[b].frames);
+        put32(buf + 18 + 8ull * b, (uint32_t)size);
+    }
+    const std::string err = emit_blocks(sp, left, right, frames, bplans, plans, nb, so.offsets.data(), buf + head,
+                                        so.payload_size, e->cfg.emit_threads);
+    if (!err.empty()) {
+        std::free(buf);
+        return fail(e, LACX_E_RUNTIME, err);
+    }
+    *out = buf;
+    *out_size = head + so.payload_size;
+    e->timing.emit_ms = ms_since(t0);
+    return LACX_OK;
+}
+
+int emit_shard(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
+               const BlockPlan* bplans, const ChannelPlan* plans, uint8_t** payload, uint64_t* payload_size,
+               uint32_t** table, uint32_t* nblocks) {
+    const auto t0 = clk::now();
+    const int channels = right ? 2 : 1;
+    const uint32_t nb = blocks_for(frames);
+    const StreamParams sp = stream_params(e->cfg, channels);
+    ShardOut so;
+    layout_payload(sp, bplans, plans, nb, so);
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(so.payload_size ? so.payload_size : 1));
+    uint32_t* tab = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * 2 * (nb ? nb : 1)));
+    if (!buf || !tab) {
+        std::free(buf);
+        std::free(tab);
+        return fail(e, LACX_E_RUNTIME, "out of memory");
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t size = ((b + 1 < nb) ? so.offsets[b + 1] : so.payload_size) - so.offsets[b];
+        tab[2 * b] = bplans[b].frames;
+        tab[2 * b + 1] = (uint32_t)size;
+    }
+    const std::string err = emit_blocks(sp, left, right, frames, bplans, plans, nb, so.offsets.data(), buf,
+                                        so.payload_size, e->cfg.emit_threads);
+    if (!err.empty()) {
+        std::free(buf);
+        std::free(tab);
+        return fail(e, LACX_E_RUNTIME, err);
+    }
+    *payload = buf;
+    *payload_size = so.payload_size;
+    *table = tab;
+    *nblocks = nb;
+    e->timing.emit_ms = ms_since(t0);
+    return LACX_OK;
+}
+
+int upload(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames) {
+    const auto t0 = clk::now();
+    int rc = ensure_pcm(e, frames, right != nullptr);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_left, left, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream), "H2D left");
+    if (right)
+        HIP_TRY(e, hipMemcpyAsync(e->d_right, right, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream),
+                "H2D right");
+    HIP_TRY(e, hipStreamSynchronize(e->stream), "H2D synchronize");
+    e->timing.h2d_ms = ms_since(t0);
+    return LACX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lacx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out) {
+    if (!cfg || !out) return LACX_E_INVALID;
+    lacx_encoder* e = new lacx_encoder();
+    e->cfg = *cfg;
+    *out = e;
+    return LACX_OK;
+}
+
+void lacx_encoder_destroy(lacx_encoder* e) {
+    if (!e) return;
+    if (e->device_ready) {
+        (void)hipSetDevice(e->device);
+        free_workspace(e);
+        if (e->d_left) (void)hipFree(e->d_left);
+        if (e->d_right) (void)hipFree(e->d_right);
+        if (e->h_plans) (void)hipHostFree(e->h_plans);
+        if (e->h_bplans) (void)hipHostFree(e->h_bplans);
+        for (auto& ev : e->ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+const char* lacx_last_error(const lacx_encoder* e) { return e ? e->err.c_str() : "null encoder"; }
+
+void lacx_free(void* p) { std::free(p); }
+
+void lacx_get_timing(const lacx_encoder* e, lacx_timing* out) {
+    if (e && out) *out = e->timing;
+}
+
+int lacx_analyze_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                        void* stream, lacx_block_plan* bplans, lacx_channel_plan* plans) {
+    if (!e) return LACX_E_INVALID;
+    int rc = validate_stream_args(e, d_left, frames);
+    if (rc) return rc;
+    rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    const int channels = d_right ? 2 : 1;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    rc = analyze_on_device(e, d_left, d_right, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, st);
+    if (rc) return rc;
+    const uint32_t nb = blocks_for(frames);
+    if (bplans) std::memcpy(bplans, e->h_bplans, (size_t)nb * sizeof(BlockPlan));
+    if (plans) std::memcpy(plans, e->h_plans, (size_t)nb * kSlotsPerBlock * sizeof(ChannelPlan));
+    return check_sample_range(e, nb);
+}
+
+int lacx_analyze(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
+                 lacx_block_plan* bplans, lacx_channel_plan* plans) {
+    if (!e) return LACX_E_INVALID;
+    int rc = validate_stream_args(e, left, frames);
+    if (rc) return rc;
+    rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    rc = upload(e, left, right, frames);
+    if (rc) return rc;
+    return lacx_analyze_device(e, e->d_left, right ? e->d_right : nullptr, frames, nullptr, bplans, plans);
+}
+
+int lacx_emit_from_plans(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
+                         const lacx_block_plan* bplans, const lacx_channel_plan* plans, uint8_t** out,
+                         uint64_t* out_size) {
+    if (!e || !out || !out_size || !bplans || !plans) return LACX_E_INVALID;
+    const int rc = validate_stream_args(e, left, frames);
+    if (rc) return rc;
+    return emit_stream(e, left, right, frames, reinterpret_cast<const BlockPlan*>(bplans),
+                       reinterpret_cast<const ChannelPlan*>(plans), out, out_size);
+}
+
+int lacx_encode_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, const int32_t* h_left,
+                       const int32_t* h_right, uint64_t frames, void* stream, uint8_t** out,
+                       uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    e->timing = lacx_timing{};
+    int rc = lacx_analyze_device(e, d_left, d_right, frames, stream, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<int32_t> tmp_l, tmp_r;
+    if (!h_left) {  // no host copy supplied: fetch the PCM for the host emit
+        tmp_l.resize(frames);
+        HIP_TRY(e, hipMemcpy(tmp_l.data(), d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
+        h_left = tmp_l.data();
+        if (d_right) {
+            tmp_r.resize(frames);
+            HIP_TRY(e, hipMemcpy(tmp_r.data(), d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
+            h_right = tmp_r.data();
+        }
+    }
+    rc = emit_stream(e, h_left, d_right ? h_right : nullptr, frames, e->h_bplans, e->h_plans, out, out_size);
+    e->timing.total_ms = ms_since(t0);
+    return rc;
+}
+
+int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames, uint8_t** out,
+                uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    e->timing = lacx_timing{};
+    int rc = validate_stream_args(e, left, frames);
+    if (rc) return rc;
+    rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    rc = upload(e, left, right, frames);
+    if (rc) return rc;
+    const double h2d = e->timing.h2d_ms;
+    rc = lacx_analyze_device(e, e->d_left, right ? e->d_right : nullptr, frames, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    rc = emit_stream(e, left, right, frames, e->h_bplans, e->h_plans, out, out_size);
+    e->timing.h2d_ms = h2d;
+    e->timing.total_ms = ms_since(t0);
+    return rc;
+}
+
+int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,
+                             const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                             uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
+    if (!e || !payload || !payload_size || !table || !nblocks || !h_left) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    e->timing = lacx_timing{};
+    int rc = lacx_analyze_device(e, d_left, d_right, frames, stream, nullptr, nullptr);
+    if (rc) return rc;
+    rc = emit_shard(e, h_left, d_right ? h_right : nullptr, frames, e->h_bplans, e->h_plans, payload, payload_size,
+                    table, nblocks);
+    e->timing.total_ms = ms_since(t0);
+    return rc;
+}
+
+int lacx_encode_shard(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
+                      uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
+    if (!e) return LACX_E_INVALID;
+    int rc = validate_stream_args(e, left, frames);
+    if (rc) return rc;
+    rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    rc = upload(e, left, right, frames);
+    if (rc) return rc;
+    return lacx_encode_shard_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr,
+                                    payload, payload_size, table, nblocks);
+}
+
+int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
+                  const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,
+                  uint8_t** out, uint64_t* out_size) {
+    if (!cfg || !out || !out_size || (channels != 1 && channels != 2)) return LACX_E_INVALID;
+    uint64_t nb = 0, pay = 0;
+    for (uint32_t s = 0; s < nshards; ++s) {
+        nb += nblocks[s];
+        pay += payload_sizes[s];
+    }
+    if (nb == 0 || nb > 0xFFFFFFFFull) return LACX_E_INVALID;
+    const uint64_t head = 10 + 4 + 8 * nb;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + pay));
+    if (!buf) return LACX_E_RUNTIME;
+    write_frame_header(stream_params(*cfg, channels), buf);
+    put32(buf + 10, (uint32_t)nb);
+    uint64_t bi = 0, off = head;
+    for (uint32_t s = 0; s < nshards; ++s) {
+        for (uint32_t b = 0; b < nblocks[s]; ++b, ++bi) {
+            if (tables[s][2 * b + 1] == 0) {
+                std::free(buf);
+                return LACX_E_RUNTIME;
+            }
+            put32(buf + 14 + 8 * bi, tables[s][2 * b]);
+            put32(buf + 18 + 8 * bi, tables[s][2 * b + 1]);
+        }
+        std::memcpy(buf + off, payloads[s], payload_sizes[s]);
+        off += payload_sizes[s];
+    }
+    *out = buf;
+    *out_size = head + pay;
+    return LACX_OK;
+}
+
+static int block_domain_check(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
+    if (n > (uint32_t)kMaxBlock) return fail(e, LACX_E_INVALID, "block larger than 16384 samples");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pcm[i] > (1 << 24) || pcm[i] < -(1 << 24))
+            return fail(e, LACX_E_INVALID, "block sample outside the supported 25-bit mid/side domain");
+    }
+    return LACX_OK;
+}
+
+static int block_analyze(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
+    int rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    rc = upload(e, pcm, nullptr, n);
+    if (rc) return rc;
+    return analyze_on_device(e, e->d_left, nullptr, n, 1, 0, /*bit_depth=*/0, e->stream);
+}
+
+int lacx_block_plan_only(lacx_encoder* e, const int32_t* pcm, uint32_t n, lacx_channel_plan* plan) {
+    if (!e || !pcm || !plan || n == 0) return LACX_E_INVALID;
+    int rc = block_domain_check(e, pcm, n);
+    if (rc) return rc;
+    rc = block_analyze(e, pcm, n);
+    if (rc) return rc;
+    std::memcpy(plan, &e->h_plans[0], sizeof(ChannelPlan));
+    return LACX_OK;
+}
+
+int lacx_block_encode(lacx_encoder* e, const int32_t* pcm, uint32_t n, uint8_t** out, uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    if (n == 0) {
+        // Block::Encoder::encode of an empty block: fixed-0, unpartitioned Rice with k=0, no residuals
+        // (type, order, control, 7 metadata bits padded): four zero bytes.
+        uint8_t* b = static_cast<uint8_t*>(std::calloc(4, 1));
+        *out = b;
+        *out_size = 4;
+        return LACX_OK;
+    }
+    if (!pcm) return LACX_E_INVALID;
+    int rc = block_domain_check(e, pcm, n);
+    if (rc) return rc;
+    rc = block_analyze(e, pcm, n);
+    if (rc) return rc;
+    const ChannelPlan& pl = e->h_plans[0];
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(pl.payload_bytes ? pl.payload_bytes : 1));
+    std::vector<int32_t> scratch(n);
+    const size_t wrote = emit_channel(pl, pcm, nullptr, CH_L, n, buf, pl.payload_bytes, scratch.data());
+    if (wrote != pl.payload_bytes) {
+        std::free(buf);
+        return fail(e, LACX_E_RUNTIME, "emitted size disagrees with the device plan (internal error)");
+    }
+    *out = buf;
+    *out_size = wrote;
+    return LACX_OK;
+}
+
+int lacx_debug_lpc(lacx_encoder* e, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
+                   uint8_t* used) {
+    if (!e || !pcm || n == 0) return LACX_E_INVALID;
+    int rc = block_domain_check(e, pcm, n);
+    if (rc) return rc;
+    rc = block_analyze(e, pcm, n);
+    if (rc) return rc;
+    LpcSet ls;
+    HIP_TRY(e, hipMemcpy(acorr, e->ws.acorr, 13 * sizeof(int64_t), hipMemcpyDeviceToHost), "D2H acorr");
+    HIP_TRY(e, hipMemcpy(&ls, e->ws.lpcs, sizeof(LpcSet), hipMemcpyDeviceToHost), "D2H lpc");
+    std::memcpy(coef, ls.coef, sizeof(ls.coef));
+    std::memcpy(used, ls.used, sizeof(ls.used));
+    return LACX_OK;
+}
+
+}  // extern "C"

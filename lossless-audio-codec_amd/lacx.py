@@ -1,0 +1,373 @@
+"""ctypes binding of liblacx.so (include/lacx.h) and Python mirrors of the reference's encoder classes.
+
+`Encoder` mirrors LAC::Encoder (ref src/codec/lac/encoder.hpp:12-43): same constructor argument
+order, the same setters, `encode(left, right)` returning the .lac bytes, ValueError where the
+reference throws std::invalid_argument and RuntimeError where it throws std::runtime_error.
+`BlockEncoder` mirrors Block::Encoder (ref src/codec/block/encoder.hpp:9-30).
+
+PyTorch is optional plumbing: `encode_tensors` takes int32 CUDA(HIP) tensors whose storage is handed
+to the library by raw pointer (no torch types cross the ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblacx.so")
+
+OK, E_INVALID, E_RUNTIME, E_DEVICE = 0, 1, 2, 3
+MAX_BLOCK = 16384
+SLOTS = 16
+CH_L, CH_R, CH_M, CH_S = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_uint32),
+        ("bit_depth", C.c_uint8),
+        ("stereo_mode", C.c_uint8),
+        ("zero_run_enabled", C.c_uint8),
+        ("partitioning_enabled", C.c_uint8),
+        ("device", C.c_int32),
+        ("emit_threads", C.c_uint32),
+    ]
+
+
+class ChannelPlan(C.Structure):
+    _fields_ = [
+        ("predictor_type", C.c_uint8),
+        ("order", C.c_uint8),
+        ("partition_order", C.c_uint8),
+        ("valid", C.c_uint8),
+        ("coef", C.c_int16 * 12),
+        ("payload_bytes", C.c_uint32),
+        ("total_bits", C.c_uint64),
+        ("part_mode_k", C.c_uint8 * 256),
+    ]
+
+
+class BlockPlan(C.Structure):
+    _fields_ = [
+        ("choose_ms", C.c_uint8),
+        ("uncertain", C.c_uint8),
+        ("est_ms", C.c_uint8),
+        ("invalid", C.c_uint8),
+        ("frames", C.c_uint32),
+        ("first_bad", C.c_uint32),
+        ("pad", C.c_uint32),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("h2d_ms", C.c_double),
+        ("analysis_ms", C.c_double),
+        ("ingest_ms", C.c_double),
+        ("probe_ms", C.c_double),
+        ("full_ms", C.c_double),
+        ("d2h_ms", C.c_double),
+        ("emit_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("full_slots", C.c_uint64),
+        ("probe_slots", C.c_uint64),
+    ]
+
+
+EXPORTS = (
+    "lacx_encoder_create", "lacx_encoder_destroy", "lacx_last_error", "lacx_free", "lacx_get_timing",
+    "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
+    "lacx_encode_shard", "lacx_encode_shard_device", "lacx_assemble", "lacx_block_encode",
+    "lacx_block_plan_only", "lacx_debug_lpc", "lacx_device_count",
+)
+
+
+def build(force: bool = False) -> str:
+    """Compiles liblacx.so in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "liblacx.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {HERE}` (or __graft_entry__.build()); "
+                "the LAC encode path has no Python/CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.lacx_last_error.restype = C.c_char_p
+        L.lacx_last_error.argtypes = [C.c_void_p]
+        L.lacx_free.argtypes = [C.c_void_p]
+        L.lacx_encoder_destroy.argtypes = [C.c_void_p]
+        L.lacx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.lacx_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().lacx_device_count())
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _raise(handle, rc):
+    msg = lib().lacx_last_error(handle).decode(errors="replace")
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def _take(ptr, size) -> bytes:
+    data = C.string_at(ptr, size.value)
+    lib().lacx_free(ptr)
+    return data
+
+
+class Encoder:
+    """Mirror of LAC::Encoder (ref src/codec/lac/encoder.hpp:12-43)."""
+
+    def __init__(self, order: int = 12, stereo_mode: int = 0, sample_rate: int = 44100, bit_depth: int = 16,
+                 debug_lpc: bool = False, debug_stereo_est: bool = False, debug_zr: bool = False,
+                 device: int = -1):
+        self.order = order  # stored and ignored, as in the reference (ref block/encoder.cpp:41)
+        self._cfg = Config(sample_rate & 0xFFFFFFFF, bit_depth & 0xFF, stereo_mode & 0xFF, 1, 1, device, 0)
+        self._raw_stereo_mode = stereo_mode
+        self._h = None
+
+    # -- setters of the reference ------------------------------------------------------------
+    def set_zero_run_enabled(self, enabled: bool):
+        self._cfg.zero_run_enabled = 1 if enabled else 0
+        self._reset()
+
+    def set_partitioning_enabled(self, enabled: bool):
+        self._cfg.partitioning_enabled = 1 if enabled else 0
+        self._reset()
+
+    def set_debug_partitions(self, enabled: bool):  # debug prints only in the reference
+        pass
+
+    def set_thread_count(self, max_threads: int):
+        self._cfg.emit_threads = int(max_threads)
+        self._reset()
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _reset(self):
+        if self._h is not None:
+            lib().lacx_encoder_destroy(self._h)
+            self._h = None
+
+    def _handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            rc = lib().lacx_encoder_create(C.byref(self._cfg), C.byref(h))
+            if rc != OK:
+                raise RuntimeError("lacx_encoder_create failed")
+            self._h = h
+        return self._h
+
+    def close(self):
+        self._reset()
+
+    def __del__(self):
+        try:
+            self._reset()
+        except Exception:
+            pass
+
+    def timing(self) -> Timing:
+        t = Timing()
+        lib().lacx_get_timing(self._handle(), C.byref(t))
+        return t
+
+    # -- LAC::Encoder::encode ------------------------------------------------------------------
+    def encode(self, left, right=None) -> bytes:
+        L, lp = _i32(left)
+        rp = None
+        if right is not None and len(right) != 0:
+            R, rp = _i32(right)
+            if R.size != L.size:
+                raise ValueError(f"right channel size ({R.size}) must match left channel size ({L.size})")
+        if L.size == 0:
+            raise ValueError("left channel must not be empty")
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._handle()
+        rc = lib().lacx_encode(h, lp, rp, C.c_uint64(L.size), C.byref(out), C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        return _take(out, size)
+
+    def analyze(self, left, right=None):
+        """Device analysis only: (block_plans, channel_plans[nblocks*16]) as ctypes arrays."""
+        L, lp = _i32(left)
+        rp = None
+        if right is not None:
+            R, rp = _i32(right)
+        nb = (L.size + MAX_BLOCK - 1) // MAX_BLOCK
+        bplans = (BlockPlan * nb)()
+        plans = (ChannelPlan * (nb * SLOTS))()
+        h = self._handle()
+        rc = lib().lacx_analyze(h, lp, rp, C.c_uint64(L.size), bplans, plans)
+        if rc != OK:
+            _raise(h, rc)
+        return bplans, plans
+
+    def emit_from_plans(self, left, right, bplans, plans) -> bytes:
+        """Host-only emit + container from plan records (no device involved)."""
+        L, lp = _i32(left)
+        rp = None
+        if right is not None:
+            R, rp = _i32(right)
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._handle()
+        rc = lib().lacx_emit_from_plans(h, lp, rp, C.c_uint64(L.size), bplans, plans, C.byref(out), C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        return _take(out, size)
+
+    def encode_shard(self, left, right=None):
+        """Block-range shard: (payload bytes, table uint32[nblocks,2])."""
+        L, lp = _i32(left)
+        rp = None
+        if right is not None:
+            R, rp = _i32(right)
+        pay = C.POINTER(C.c_uint8)()
+        psize = C.c_uint64()
+        tab = C.POINTER(C.c_uint32)()
+        nb = C.c_uint32()
+        h = self._handle()
+        rc = lib().lacx_encode_shard(h, lp, rp, C.c_uint64(L.size), C.byref(pay), C.byref(psize), C.byref(tab),
+                                     C.byref(nb))
+        if rc != OK:
+            _raise(h, rc)
+        table = np.ctypeslib.as_array(tab, shape=(nb.value, 2)).copy()
+        lib().lacx_free(tab)
+        return _take(pay, psize), table
+
+    # device-resident entry points (raw pointers; torch tensors welcome) -----------------------
+    def encode_device(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
+                      stream: int = 0) -> bytes:
+        hl, hlp = _i32(h_left)
+        hrp = None
+        if h_right is not None:
+            hr, hrp = _i32(h_right)
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._handle()
+        rc = lib().lacx_encode_device(h, C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr or 0), hlp, hrp,
+                                      C.c_uint64(frames), C.c_void_p(stream), C.byref(out), C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        return _take(out, size)
+
+    def analyze_device(self, d_left_ptr: int, d_right_ptr: int | None, frames: int, stream: int = 0):
+        """Runs the kernels on device-resident PCM and returns nothing (plans stay in the encoder)."""
+        h = self._handle()
+        rc = lib().lacx_analyze_device(h, C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr or 0), C.c_uint64(frames),
+                                       C.c_void_p(stream), None, None)
+        if rc != OK:
+            _raise(h, rc)
+
+    def encode_shard_device(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
+                            stream: int = 0):
+        hl, hlp = _i32(h_left)
+        hrp = None
+        if h_right is not None:
+            hr, hrp = _i32(h_right)
+        pay = C.POINTER(C.c_uint8)()
+        psize = C.c_uint64()
+        tab = C.POINTER(C.c_uint32)()
+        nb = C.c_uint32()
+        h = self._handle()
+        rc = lib().lacx_encode_shard_device(h, C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr or 0), hlp, hrp,
+                                            C.c_uint64(frames), C.c_void_p(stream), C.byref(pay), C.byref(psize),
+                                            C.byref(tab), C.byref(nb))
+        if rc != OK:
+            _raise(h, rc)
+        table = np.ctypeslib.as_array(tab, shape=(nb.value, 2)).copy()
+        lib().lacx_free(tab)
+        return _take(pay, psize), table
+
+
+def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:
+    """Header + block table + payload concat of (payload, table) shards given in stream order
+    (ref src/codec/lac/encoder.cpp:243-250, 445-465)."""
+    cfg = Config(sample_rate, bit_depth, stereo_mode, 1, 1, -1, 0)
+    n = len(shards)
+    pays = (C.c_char_p * n)(*[s[0] for s in shards])
+    sizes = (C.c_uint64 * n)(*[len(s[0]) for s in shards])
+    tabs_np = [np.ascontiguousarray(s[1], dtype=np.uint32) for s in shards]
+    tabs = (C.POINTER(C.c_uint32) * n)(*[t.ctypes.data_as(C.POINTER(C.c_uint32)) for t in tabs_np])
+    nbs = (C.c_uint32 * n)(*[t.shape[0] for t in tabs_np])
+    out = C.POINTER(C.c_uint8)()
+    size = C.c_uint64()
+    rc = lib().lacx_assemble(C.byref(cfg), channels, n, C.cast(pays, C.POINTER(C.POINTER(C.c_uint8))), sizes, tabs,
+                             nbs, C.byref(out), C.byref(size))
+    if rc != OK:
+        raise RuntimeError("lacx_assemble failed")
+    return _take(out, size)
+
+
+class BlockEncoder:
+    """Mirror of Block::Encoder (ref src/codec/block/encoder.hpp:9-30)."""
+
+    def __init__(self, order: int = 12, debug_lpc: bool = False, debug_zr: bool = False, device: int = -1):
+        self._enc = Encoder(order, 0, 48000, 24, device=device)
+
+    def set_zero_run_enabled(self, enabled: bool):
+        self._enc.set_zero_run_enabled(enabled)
+
+    def set_partitioning_enabled(self, enabled: bool):
+        self._enc.set_partitioning_enabled(enabled)
+
+    def set_debug_block_index(self, index: int):
+        pass
+
+    def set_debug_partitions(self, enabled: bool):
+        pass
+
+    def encode(self, pcm) -> bytes:
+        P, pp = _i32(pcm)
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._enc._handle()
+        rc = lib().lacx_block_encode(h, pp, C.c_uint32(P.size), C.byref(out), C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        return _take(out, size)
+
+    def plan(self, pcm) -> ChannelPlan:
+        P, pp = _i32(pcm)
+        plan = ChannelPlan()
+        h = self._enc._handle()
+        rc = lib().lacx_block_plan_only(h, pp, C.c_uint32(P.size), C.byref(plan))
+        if rc != OK:
+            _raise(h, rc)
+        return plan
+
+    def debug_lpc(self, pcm):
+        P, pp = _i32(pcm)
+        ac = np.zeros(13, dtype=np.int64)
+        coef = np.zeros((5, 13), dtype=np.int16)
+        used = np.zeros(5, dtype=np.uint8)
+        h = self._enc._handle()
+        rc = lib().lacx_debug_lpc(h, pp, C.c_uint32(P.size), ac.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  coef.ctypes.data_as(C.POINTER(C.c_int16)),
+                                  used.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != OK:
+            _raise(h, rc)
+        return ac, coef, used

@@ -1,0 +1,183 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Bit-exact is the bar everywhere: bytes of the .lac, plan records, autocorrelation, Q15 coefficients.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.lacx.device_count() < 1:
+        pytest.fail("no HIP device visible: GPU tests need an MI355X (the product has no CPU fallback)")
+    return pkg
+
+
+def _ms(l, r):
+    m = ((l.astype(np.int64) + r) >> 1).astype(np.int32)
+    s = (l - r).astype(np.int32)
+    return m, s
+
+
+KINDS = ["music", "noise", "silence", "near_silence", "sparse", "ramp", "walk", "tone", "mixed"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("bit_depth", [16, 24])
+def test_lpc_kernels_match_oracle(gpu, oracle, kind, bit_depth):
+    """k_ingest autocorrelation (exact int64) and k_levinson (software x87) vs the oracle's long double."""
+    left, right = gpu.synth.synth_pcm(16384 + 300, 2, bit_depth, 48000, seed=21, kind=kind)
+    m, s = _ms(left, right)
+    be = gpu.lacx.BlockEncoder()
+    for x in (left[:16384], s[:16384], m[16384:], left[100:100 + 256], s[5:18]):
+        ac, coef, used = be.debug_lpc(x)
+        assert np.array_equal(ac, oracle.autocorr(x, 12))
+        mvo = min(32, x.size - 1)
+        for ci, cand in enumerate((4, 6, 8, 10, 12)):
+            if cand > mvo:
+                assert used[ci] == 0
+                continue
+            ou, oc = oracle.lpc_analyze(x, cand)
+            assert used[ci] == ou
+            assert np.array_equal(coef[ci][1:cand + 1], oc[1:cand + 1])
+
+
+def _check_plan(pl, op, nbytes):
+    assert pl.valid == 1
+    assert (pl.predictor_type, pl.order, pl.partition_order, pl.total_bits) == \
+        (op.predictor_type, op.order, op.partition_order, op.total_bits)
+    if op.predictor_type == 2:
+        assert [pl.coef[i] for i in range(op.order)] == [op.coeffs_q15[i + 1] for i in range(op.order)]
+    assert [pl.part_mode_k[i] for i in range(op.part_count)] == \
+        [(op.part_mode[i] << 5) | op.part_k[i] for i in range(op.part_count)]
+    assert pl.payload_bytes == nbytes
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_block_plans_match_oracle(gpu, oracle, kind):
+    """k_analyze<16,1024> decisions (predictor, coefficients, partition order, modes, k, exact bits)."""
+    left, right = gpu.synth.synth_pcm(16384 * 2 + 777, 2, 24, 96000, seed=33, kind=kind)
+    m, s = _ms(left, right)
+    be = gpu.lacx.BlockEncoder()
+    for x in (left[:16384], s[16384:32768], m[32768:], right[3:4100], left[7:40], s[9:40], m[:1], left[:2],
+              right[:13], s[1000:1256], left[:13312], m[:12289]):
+        pl = be.plan(x)
+        _check_plan(pl, oracle.block_plan(x), len(oracle.block_encode(x)))
+        assert be.encode(x) == oracle.block_encode(x)
+
+
+def test_block_flags(gpu, oracle):
+    left, right = gpu.synth.synth_pcm(16384, 2, 16, 48000, seed=4, kind="mixed")
+    for zr in (False, True):
+        for pt in (False, True):
+            be = gpu.lacx.BlockEncoder()
+            be.set_zero_run_enabled(zr)
+            be.set_partitioning_enabled(pt)
+            for x in (left, np.zeros(5000, np.int32), (right // 4096).astype(np.int32)):
+                assert be.encode(x) == oracle.block_encode(x, zr, pt)
+    assert gpu.lacx.BlockEncoder().encode(np.zeros(0, np.int32)) == oracle.block_encode(np.zeros(0, np.int32))
+
+
+STREAMS = [
+    # frames, channels, bit_depth, rate, stereo_mode, kind, stereo
+    (16384 * 5 + 37, 2, 16, 48000, 2, "music", "wide"),
+    (16384 * 4 + 4000, 2, 24, 96000, 2, "mixed", "wide"),
+    (16384 * 3, 2, 16, 44100, 2, "noise", "independent"),
+    (16384 * 2 + 1, 2, 24, 192000, 2, "music", "narrow"),
+    (16384 * 3 + 100, 2, 16, 48000, 0, "mixed", "wide"),
+    (16384 * 3 + 100, 2, 16, 48000, 1, "mixed", "wide"),
+    (16384 * 3 + 5000, 1, 16, 48000, 0, "mixed", "wide"),
+    (2400, 1, 16, 48000, 0, "tone", "wide"),  # BASELINE config 1 shape
+    (1, 2, 16, 48000, 2, "noise", "wide"),
+    (31, 2, 24, 48000, 2, "music", "identical"),
+    (33, 2, 16, 48000, 2, "music", "anticorr"),
+    (257, 2, 16, 48000, 2, "walk", "wide"),
+    (4096, 2, 16, 48000, 2, "noise", "independent"),
+    (4097, 2, 16, 48000, 2, "noise", "independent"),
+    (16384 + 300, 2, 16, 48000, 2, "silence", "identical"),
+    (16384 * 2, 2, 24, 48000, 2, "sparse", "half_silent"),
+    (16384 * 2 + 9, 2, 16, 96000, 2, "near_silence", "independent"),
+]
+
+
+@pytest.mark.parametrize("case", STREAMS, ids=lambda c: "-".join(map(str, c)))
+def test_stream_bytes_match_oracle(gpu, oracle, case):
+    frames, ch, bd, sr, sm, kind, st = case
+    left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=frames % 97 + 3, kind=kind, stereo=st)
+    enc = gpu.lacx.Encoder(12, sm, sr, bd)
+    got = enc.encode(left, right)
+    want = oracle.encode(left, right, sr, bd, sm, threads=8)
+    assert got == want
+    l2, r2, hdr = oracle.decode(got)
+    assert np.array_equal(l2, left)
+    if ch == 2:
+        assert np.array_equal(r2, right)
+
+
+def test_stream_flags_and_errors(gpu, oracle):
+    left, right = gpu.synth.synth_pcm(16384 * 2 + 50, 2, 16, 48000, seed=8, kind="mixed")
+    for zr in (False, True):
+        for pt in (False, True):
+            enc = gpu.lacx.Encoder(12, 2, 48000, 16)
+            enc.set_zero_run_enabled(zr)
+            enc.set_partitioning_enabled(pt)
+            assert enc.encode(left, right) == oracle.encode(left, right, 48000, 16, 2, zr, pt)
+    # error behaviour of LAC::Encoder::encode (ref src/codec/lac/encoder.cpp:220-241)
+    with pytest.raises(ValueError, match="left channel must not be empty"):
+        gpu.lacx.Encoder(12, 2, 48000, 16).encode(np.zeros(0, np.int32), None)
+    with pytest.raises(ValueError, match="must match left channel size"):
+        gpu.lacx.Encoder(12, 2, 48000, 16).encode(left, right[:-1])
+    with pytest.raises(ValueError, match="unsupported sample rate"):
+        gpu.lacx.Encoder(12, 2, 22050, 16).encode(left, right)
+    with pytest.raises(ValueError, match="unsupported bit depth"):
+        gpu.lacx.Encoder(12, 2, 48000, 20).encode(left, right)
+    with pytest.raises(ValueError, match="unsupported stereo mode"):
+        gpu.lacx.Encoder(12, 3, 48000, 16).encode(left, right)
+    bad = right.copy()
+    bad[16384 + 7] = 40000
+    with pytest.raises(ValueError, match=r"right sample at index 16391 is outside"):
+        gpu.lacx.Encoder(12, 2, 48000, 16).encode(left, bad)
+    bad2 = left.copy()
+    bad2[20000] = -40000
+    with pytest.raises(ValueError, match=r"left sample at index 20000 is outside"):
+        gpu.lacx.Encoder(12, 2, 48000, 16).encode(bad2, bad)
+
+
+def test_shards_concatenate_to_the_whole_stream(gpu, oracle):
+    """Block-range split (multi-GPU path): shard payloads + tables assemble to the one-shot bytes."""
+    left, right = gpu.synth.synth_pcm(16384 * 7 + 321, 2, 16, 48000, seed=12, kind="mixed")
+    whole = gpu.lacx.Encoder(12, 2, 48000, 16).encode(left, right)
+    for cuts in ([3 * 16384], [16384, 5 * 16384], [2 * 16384, 4 * 16384, 6 * 16384]):
+        bounds = [0] + cuts + [left.size]
+        shards = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            shards.append(gpu.lacx.Encoder(12, 2, 48000, 16).encode_shard(left[a:b], right[a:b]))
+        assert gpu.lacx.assemble(48000, 16, 2, 2, shards) == whole
+    assert whole == oracle.encode(left, right, 48000, 16, 2, threads=8)
+
+
+def test_golden_digests(gpu):
+    """Full-size BASELINE configs against digests minted from the unmodified reference build."""
+    path = os.path.join(GOLDEN, "digests.json")
+    if not os.path.exists(path):
+        pytest.skip("no golden digests committed")
+    with open(path) as f:
+        entries = json.load(f)
+    for ent in entries:
+        if ent.get("gpu_test", True) is False:
+            continue
+        g = ent["gen"]
+        left, right = gpu.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"],
+                                          seed=g["seed"], kind=g["kind"], stereo=g.get("stereo", "wide"))
+        enc = gpu.lacx.Encoder(12, ent["stereo_mode"], g["sample_rate"], g["bit_depth"])
+        got = enc.encode(left, right)
+        assert len(got) == ent["lac_bytes"], ent["name"]
+        assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], ent["name"]
