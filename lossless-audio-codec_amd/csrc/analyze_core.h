@@ -15,6 +15,11 @@
 //     wave ballots per block, and group prefix tables per partition (ref block/encoder.cpp:121-188);
 //   * zero runs are resolved with a block prefix-max of "last non-zero index" and a 3-sample lookahead.
 //
+// Data layout in LDS: sample j of the slot lives at word sw(j) = (j mod CH) * T + (j div CH), i.e.
+// element i of every thread's chunk forms one contiguous row of T words.  A wave reading "its" element
+// i touches 64 consecutive words (conflict-free), and so do the window taps j-256 / j-96 (same row,
+// 256/CH resp. 96/CH words to the left).
+//
 // The functions here are plain per-thread code (no cross-lane operations) so that the same text is
 // compiled into the HIP kernel (kernels.hip) and into the lock-step host simulator used by the CPU
 // tests (tests/native/sim_analyze.cpp).  Cross-thread steps (block scans, ballots, LDS atomics) live in
@@ -41,6 +46,12 @@ struct Geo {
     static_assert(MAXN % 64 == 0, "whole groups");
 };
 
+// transposed LDS index of sample j (j >= 0)
+template <class G>
+LACX_HD int sw(int j) {
+    return (j % G::CH) * G::T + (j / G::CH);
+}
+
 // Where a slot's samples come from: a plain channel, or M/S derived on the fly
 // (ref src/codec/simd/neon.cpp:14-30: M = (L+R)>>1 arithmetic, S = L-R).
 struct SlotSrc {
@@ -59,6 +70,14 @@ LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
 
 LACX_HD uint32_t zigzag32(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
 
+LACX_HD int clz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)v);
+#else
+    return v ? __builtin_clz(v) : 32;
+#endif
+}
+
 // Rice parameter of Rice::adapt_k / adapt_k_stateless before biasing:
 //   mean = (S + (c>>1)) / c ; k = mean <= 1 ? 0 : bit_width(mean-1)       (ref rice.hpp:68-71,
 //   block/encoder.cpp:72-77) == the smallest k with mean <= 2^k, i.e. with (X - c) < (c << k), X = S + (c>>1).
@@ -69,9 +88,69 @@ LACX_HD uint32_t kmean(uint64_t S, uint32_t c) {
     const int g = clz64((uint64_t)c) - clz64(Y);  // bit_width(Y) - bit_width(c) >= 0
     return (uint32_t)g + ((Y >> g) >= c ? 1u : 0u);
 }
+// same, for S + (c>>1) < 2^32
+LACX_HD uint32_t kmean32(uint32_t S, uint32_t c) {
+    const uint32_t X = S + (c >> 1);
+    const uint32_t Y = X - c;
+    const int g = clz32(c) - clz32(Y);
+    const uint32_t k = (uint32_t)g + ((Y >> (g & 31)) >= c ? 1u : 0u);
+    return (X < 2u * c) ? 0u : k;
+}
+
+template <bool NARROW>
+LACX_HD uint32_t kmean_t(uint64_t S, uint32_t c) {
+    return NARROW ? kmean32((uint32_t)S, c) : kmean(S, c);
+}
 
 LACX_HD uint64_t rice_cost(uint32_t u, uint32_t k) {  // ref block/encoder.cpp:67-70
     return (uint64_t)((k >= 31u) ? 0u : (u >> k)) + 1u + k;
+}
+
+// Bias of Rice::adapt_k (ref rice.hpp:83-113) applied to the unbiased km after `c` samples:
+//   P = sum of u over [0,c), W = sum over [0, c-256), flag counts d = large | zero<<16 over the last 96.
+// Division-free: with mean = floor(X/c), X = P + (c>>1):
+//   3L > 4 mean  <=>  X < ceil(3L/4) * c          4L+3 < 3 mean  <=>  X >= (floor((4L+3)/3) + 1) * c
+template <bool NARROW>
+LACX_HD uint32_t biased_k(uint32_t km, uint64_t P, uint64_t W, uint32_t d, uint32_t c) {
+    int bias = 0;
+    if (c > 256u) {
+        if (NARROW) {
+            const uint32_t X = (uint32_t)P + (c >> 1);
+            const uint32_t L = (((uint32_t)P - (uint32_t)W) + 128u) >> 8;
+            const uint32_t U = (3u * L + 3u) >> 2;
+            const uint32_t D = L + (L + 3u) / 3u + 1u;
+            if (X >= c) {
+                if ((uint64_t)X < (uint64_t)U * c) {
+                    bias = 1;
+                } else if ((uint64_t)X >= (uint64_t)D * c) {
+                    bias = -1;
+                }
+            }
+        } else {
+            const uint64_t X = P + (c >> 1);
+            const uint64_t L = ((P - W) + 128u) >> 8;
+            const uint64_t U = (3u * L + 3u) >> 2;
+            const uint64_t D = L + (L + 3u) / 3u + 1u;
+            if (X >= c) {
+                if (X < U * c) {
+                    bias = 1;
+                } else if (X >= D * c) {
+                    bias = -1;
+                }
+            }
+        }
+    }
+    if (c >= 96u) {
+        const uint32_t large = d & 0xFFFFu, zero = d >> 16;
+        if (large * 4u >= 288u) {
+            bias = (bias + 1 < 1) ? bias + 1 : 1;
+        } else if (zero * 5u >= 384u) {
+            bias = (bias - 1 > -1) ? bias - 1 : -1;
+        }
+    }
+    int bk = (int)km + bias;
+    bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
+    return (uint32_t)bk;
 }
 
 struct SegInfo {
@@ -81,9 +160,24 @@ struct SegInfo {
     uint8_t pad[6];
 };
 
+// Partition-search scratch; aliases the staged samples, which are dead once the winning residual is in u[].
+template <class G>
+struct PartMem {
+    uint32_t grp[15][G::NG + 1];  // packed (two 16-bit fields) plane counts per 64-sample group -> prefix
+    SegInfo seginfo[G::NSEG];
+    unsigned long long segacc[G::NSEG][3];
+    uint32_t segrun[G::NSEG];
+    uint8_t choice[G::NSEG];
+    unsigned long long pbits[G::MAXP + 1];
+};
+
 template <class G>
 struct Smem {
-    uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate; bits 30/31 = micro flags
+    uint32_t u[G::MAXN];  // zigzag residual of the current candidate (transposed); bits 30/31 = micro flags
+    union XP {
+        int32_t x[G::MAXN];  // staged samples (transposed), zero beyond n
+        PartMem<G> part;
+    } xp;
     uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
     uint32_t tabF[G::T + 1];  // in: packed chunk flag counts; after scan: exclusive prefix
@@ -99,13 +193,6 @@ struct Smem {
     int32_t best_cand;
     uint32_t cur_k0;
     LpcSet lpc;
-    // partition search
-    uint32_t grp[15][G::NG + 1];  // packed (two 16-bit fields) plane counts per 64-sample group -> prefix
-    SegInfo seginfo[G::NSEG];
-    unsigned long long segacc[G::NSEG][3];
-    uint32_t segrun[G::NSEG];
-    uint8_t choice[G::NSEG];
-    unsigned long long pbits[G::MAXP + 1];
 };
 
 template <class G>
@@ -113,67 +200,30 @@ struct Thread {
     int tid;
     int a;       // first sample of the chunk
     uint32_t n;  // samples in the slot
-    int32_t xh[G::CH + 12];  // xh[12 + i] = x[a + i]; xh[0..11] = history (0 before the slot start)
-    uint32_t u[G::CH];
-    uint32_t kf[G::CH];      // km | is_large << 8 | is_zero << 9
-    uint32_t cs[G::LV];      // bit-sliced per-plane counts of this chunk
+    int cnt;     // samples of the chunk inside the slot (0..CH)
+    uint32_t cs[G::LV];  // bit-sliced per-plane counts of this chunk
     unsigned long long crice, cbin, czr;  // chunk partial costs
     uint32_t chasrun;
 };
 
-// ---------------------------------------------------------------------------------------------
-// sample load
-// ---------------------------------------------------------------------------------------------
 template <class G>
-LACX_HD void load_chunk(Thread<G>& th, const SlotSrc& src, int64_t start, uint32_t n, int tid) {
+LACX_HD void thread_init(Thread<G>& th, uint32_t n, int tid) {
     th.tid = tid;
     th.a = tid * G::CH;
     th.n = n;
-#pragma unroll
-    for (int i = 0; i < G::CH + 12; ++i) {
-        const int64_t j = (int64_t)th.a - 12 + i;
-        th.xh[i] = (j >= 0 && j < (int64_t)n) ? slot_fetch(src, start + j) : 0;
-    }
+    const int rem = (int)n - th.a;
+    th.cnt = rem < 0 ? 0 : (rem > G::CH ? G::CH : rem);
 }
 
 // ---------------------------------------------------------------------------------------------
-// residuals.  cand 0..4 fixed orders (ref block/encoder.cpp:265-295), 5 FIR {3,-1}>>2 (:297-309),
-// 6..10 LPC orders 4..12 with open-loop Q15 prediction (ref lpc/lpc.cpp:38-61).
+// sample staging: x[sw(j)] = sample j (0 beyond n)
 // ---------------------------------------------------------------------------------------------
 template <class G>
-LACX_HD void residual_chunk(Thread<G>& th, int cand, const LpcSet& lpc) {
-    const int32_t* x = th.xh + 12;
+LACX_HD void stage_samples(const Thread<G>& th, Smem<G>& sh, const SlotSrc& src, int64_t start) {
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         const int j = th.a + i;
-        int32_t r;
-        if (cand <= 4) {
-            int64_t pred = 0;
-            if (j >= cand) {
-                switch (cand) {
-                    case 1: pred = x[i - 1]; break;
-                    case 2: pred = 2LL * x[i - 1] - x[i - 2]; break;
-                    case 3: pred = 3LL * x[i - 1] - 3LL * x[i - 2] + x[i - 3]; break;
-                    case 4: pred = 4LL * x[i - 1] - 6LL * x[i - 2] + 4LL * x[i - 3] - x[i - 4]; break;
-                    default: break;
-                }
-            }
-            r = (int32_t)((int64_t)x[i] - pred);
-        } else if (cand == 5) {
-            int64_t pred = 0;
-            if (j >= 2) pred = (3LL * (int64_t)x[i - 1] - (int64_t)x[i - 2]) >> 2;
-            r = (int32_t)((int64_t)x[i] - pred);
-        } else {
-            const int ci = cand - 6;
-            const int ord = lpc.used[ci];
-            int64_t acc = 0;
-#pragma unroll
-            for (int t = 1; t <= 12; ++t) {
-                if (t <= ord) acc += (int64_t)lpc.coef[ci][t] * (int64_t)x[i - t];
-            }
-            r = (int32_t)((int64_t)x[i] - (acc >> 15));
-        }
-        th.u[i] = ((uint32_t)j < th.n) ? zigzag32(r) : 0u;
+        sh.xp.x[i * G::T + th.tid] = ((uint32_t)j < th.n) ? slot_fetch(src, start + j) : 0;
     }
 }
 
@@ -190,38 +240,95 @@ LACX_HD void sliced_add(const uint32_t* a, const uint32_t* b, uint32_t* out /* W
     out[W] = carry;
 }
 
-// Phase R: chunk sum, last non-zero index, bit-sliced plane counts of th.u[].
 template <class G>
-LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh) {
-    uint64_t s = 0;
-    int32_t lastnz = -1;
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        s += th.u[i];
-        if (th.u[i] != 0) lastnz = th.a + i;
-    }
-    sh.tabP[th.tid] = s;
-    sh.tabNZ[th.tid] = lastnz;
-    // plane counts: pairwise tree of bit-sliced adders
+LACX_HD void plane_counts(const uint32_t* u, uint32_t* cs) {
     if (G::CH == 16) {
         uint32_t l1[8][2], l2[4][3], l3[2][4], l4[5];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sliced_add<1>(&th.u[2 * i], &th.u[2 * i + 1], l1[i]);
+        for (int i = 0; i < 8; ++i) sliced_add<1>(&u[2 * i], &u[2 * i + 1], l1[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) sliced_add<2>(l1[2 * i], l1[2 * i + 1], l2[i]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) sliced_add<3>(l2[2 * i], l2[2 * i + 1], l3[i]);
         sliced_add<4>(l3[0], l3[1], l4);
 #pragma unroll
-        for (int l = 0; l < G::LV; ++l) th.cs[l] = l4[l];
-    } else if (G::CH == 4) {
+        for (int l = 0; l < G::LV; ++l) cs[l] = l4[l];
+    } else {
         uint32_t l1[2][2], l2[3];
-        sliced_add<1>(&th.u[0], &th.u[1], l1[0]);
-        sliced_add<1>(&th.u[2], &th.u[3], l1[1]);
+        sliced_add<1>(&u[0], &u[1], l1[0]);
+        sliced_add<1>(&u[2], &u[3], l1[1]);
         sliced_add<2>(l1[0], l1[1], l2);
 #pragma unroll
-        for (int l = 0; l < G::LV; ++l) th.cs[l] = l2[l];
+        for (int l = 0; l < G::LV; ++l) cs[l] = l2[l];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase R: residual of candidate `cand` over the chunk -> u[] in LDS (plain, no flags), chunk sum,
+// last non-zero index, bit-sliced plane counts.
+// cand 0..4 fixed orders (ref block/encoder.cpp:265-295), 5 FIR {3,-1}>>2 (:297-309), 6..10 LPC orders
+// 4..12 with open-loop Q15 prediction and zero history before the slot (ref lpc/lpc.cpp:38-61).
+// Fixed differences are taken in wrapping 32-bit arithmetic: the true values fit int32 for
+// |x| <= 2^24, so the low 32 bits equal the reference's int64 results.
+// ---------------------------------------------------------------------------------------------
+template <class G>
+LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh, int cand) {
+    int32_t xh[G::CH + 12];
+#pragma unroll
+    for (int i = 0; i < G::CH + 12; ++i) {
+        const int j = th.a - 12 + i;
+        xh[i] = (j >= 0) ? sh.xp.x[sw<G>(j < 0 ? 0 : j)] : 0;
+    }
+    const int32_t* x = xh + 12;
+    uint32_t u[G::CH];
+    if (cand <= 4) {
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) {
+            const int j = th.a + i;
+            const uint32_t x0 = (uint32_t)x[i], x1 = (uint32_t)x[i - 1], x2 = (uint32_t)x[i - 2],
+                           x3 = (uint32_t)x[i - 3], x4 = (uint32_t)x[i - 4];
+            uint32_t r = x0;
+            if (cand == 1) r = x0 - x1;
+            if (cand == 2) r = x0 - 2u * x1 + x2;
+            if (cand == 3) r = x0 - 3u * x1 + 3u * x2 - x3;
+            if (cand == 4) r = x0 - 4u * x1 + 6u * x2 - 4u * x3 + x4;
+            if (j < cand) r = x0;  // warm-up samples are stored raw
+            u[i] = (i < th.cnt) ? zigzag32((int32_t)r) : 0u;
+        }
+    } else if (cand == 5) {
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) {
+            const int j = th.a + i;
+            const int64_t pred = (3LL * (int64_t)x[i - 1] - (int64_t)x[i - 2]) >> 2;
+            const int32_t r = (j >= 2) ? (int32_t)((int64_t)x[i] - pred) : x[i];
+            u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
+        }
+    } else {
+        const int ci = cand - 6;
+        const int ord = sh.lpc.used[ci];
+        int32_t c[13];
+#pragma unroll
+        for (int t = 1; t <= 12; ++t) c[t] = (t <= ord) ? (int32_t)sh.lpc.coef[ci][t] : 0;
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) {
+            int64_t acc = 0;
+#pragma unroll
+            for (int t = 1; t <= 12; ++t) acc += (int64_t)c[t] * (int64_t)x[i - t];
+            const int32_t r = (int32_t)((int64_t)x[i] - (acc >> 15));
+            u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
+        }
+    }
+    uint64_t s = 0;
+    int32_t lastnz = -1;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        s += u[i];
+        if (u[i] != 0) lastnz = th.a + i;
+        sh.u[i * G::T + th.tid] = u[i];
+    }
+    sh.tabP[th.tid] = s;
+    sh.tabNZ[th.tid] = lastnz;
+    plane_counts<G>(u, th.cs);
 }
 
 // Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.
@@ -262,155 +369,85 @@ LACX_HD uint32_t pick_static_k(const uint64_t* A, uint32_t m, uint64_t* bits) {
     return best_k;
 }
 
-// Phase A: unbiased k after every sample, micro-window flags (ref rice.hpp:68-80).
-template <class G>
+// Phase A: unbiased k after every sample -> micro-window flags into bits 30/31 of u (ref rice.hpp:68-80),
+// and the chunk's packed flag counts.
+template <class G, bool NARROW>
 LACX_HD void phase_a(Thread<G>& th, Smem<G>& sh) {
     uint64_t P = sh.tabP[th.tid];
     uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        const uint32_t j = (uint32_t)(th.a + i);
-        if (j < th.n) {
-            P += th.u[i];
-            const uint32_t km = kmean(P, j + 1u);
-            const uint32_t q = (km >= 31u) ? 0u : (th.u[i] >> km);
-            const uint32_t fl = q > 3u, fz = q == 0u;
-            th.kf[i] = km | (fl << 8) | (fz << 9);
-            sh.u[j] = th.u[i] | (fl << 30) | (fz << 31);
-            cnt += fl + (fz << 16);
-        } else {
-            th.kf[i] = 0;
-        }
+    uint32_t c = (uint32_t)th.a;
+    for (int i = 0; i < th.cnt; ++i) {
+        const uint32_t u = sh.u[i * G::T + th.tid];
+        P += u;
+        ++c;
+        const uint32_t km = kmean_t<NARROW>(P, c);
+        const uint32_t q = u >> km;  // km <= 31 and u < 2^30
+        const uint32_t fl = q > 3u, fz = q == 0u;
+        sh.u[i * G::T + th.tid] = u | (fl << 30) | (fz << 31);
+        cnt += fl + (fz << 16);
     }
     sh.tabF[th.tid] = cnt;
 }
 
-// Plain (flag-free) copy of the chunk's u into shared memory, for the partition search.
+// Sample j as seen by the zero-run lookahead: its u, or 1 ("not a zero") at/after `limit`.
 template <class G>
-LACX_HD void store_u_plain(const Thread<G>& th, Smem<G>& sh) {
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        const uint32_t j = (uint32_t)(th.a + i);
-        if (j < th.n) sh.u[j] = th.u[i];
-    }
-}
-
-// zero-run helpers -----------------------------------------------------------------------------
-// ext[i] for i in [0, CH+3): is sample a+i a non-zero or outside [.., limit) ?
-template <class G>
-LACX_HD void load_lookahead(const Thread<G>& th, const Smem<G>& sh, uint32_t* la) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const uint32_t j = (uint32_t)(th.a + G::CH + i);
-        la[i] = (j < th.n) ? (sh.u[j] & 0x3FFFFFFFu) : 1u;
-    }
+LACX_HD uint32_t peek_u(const Smem<G>& sh, int j, uint32_t limit) {
+    const int jj = ((uint32_t)j < limit) ? j : 0;
+    const uint32_t v = sh.u[sw<G>(jj)] & 0x3FFFFFFFu;
+    return ((uint32_t)j < limit) ? v : 1u;
 }
 
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
 // (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
-template <class G>
+template <class G, bool NARROW>
 LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     const int t = th.tid;
+    const uint32_t n = th.n;
     uint64_t P = sh.tabP[t];                                   // P_{a-1}
     uint64_t W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;    // P_{a-1-256}
     uint32_t F = sh.tabF[t];                                   // flag counts over [0, a-1]
     uint32_t F96 = (t >= G::W96) ? sh.tabF[t - G::W96] : 0;    // ... over [0, a-1-96]
-    uint32_t la[3];
-    load_lookahead(th, sh, la);
-    uint32_t kprev = k0;
-    if (th.a > 0 && (uint32_t)th.a < th.n) {
-        // k returned after sample a-1 (count c = a)
-        const uint32_t c = (uint32_t)th.a;
-        const uint32_t km = kmean(P, c);
-        int bias = 0;
-        const uint64_t X = P + (c >> 1);
-        if (c > 256u && X >= c) {
-            const uint64_t L = ((P - W) + 128u) >> 8;
-            const uint64_t U = (3u * L + 3u) >> 2;
-            const uint64_t D = L + (L + 3u) / 3u + 1u;
-            if (X < U * c) {
-                bias = 1;
-            } else if (X >= D * c) {
-                bias = -1;
-            }
-        }
-        if (c >= 96u) {
-            const uint32_t d = F - F96;
-            const uint32_t large = d & 0xFFFFu, zero = d >> 16;
-            if (large * 4u >= 288u) {
-                bias = (bias + 1 < 1) ? bias + 1 : 1;
-            } else if (zero * 5u >= 384u) {
-                bias = (bias - 1 > -1) ? bias - 1 : -1;
-            }
-        }
-        int bk = (int)km + bias;
-        bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
-        kprev = (uint32_t)bk;
-    }
-    // zeros ending just before the chunk
-    int32_t f = th.a - 1 - sh.tabNZ[t];
+    const bool has256 = t >= G::W256, has96 = t >= G::W96;
+    uint32_t c = (uint32_t)th.a;
+    // k in force for the first sample of the chunk: the value returned after sample a-1
+    uint32_t kin = k0;
+    if (th.a > 0 && th.cnt > 0) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+    int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        const uint32_t j = (uint32_t)(th.a + i);
-        if (j < th.n) {
-            const uint32_t u = th.u[i];
-            const uint32_t kin = (j == 0) ? k0 : kprev;
-            const uint64_t rc = rice_cost(u, kin);
-            rice += rc;
-            bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
-            // run structure
-            const bool z = (u == 0);
-            f = z ? f + 1 : 0;
-            // next three samples: non-zero or outside the block?
-            const uint32_t n1 = (i + 1 < G::CH) ? (((uint32_t)(j + 1) < th.n) ? th.u[(i + 1 < G::CH) ? i + 1 : 0] : 1u) : la[(i + 1 - G::CH) < 0 ? 0 : (i + 1 - G::CH)];
-            const uint32_t n2 = (i + 2 < G::CH) ? (((uint32_t)(j + 2) < th.n) ? th.u[(i + 2 < G::CH) ? i + 2 : 0] : 1u) : la[(i + 2 - G::CH) < 0 ? 0 : (i + 2 - G::CH)];
-            const uint32_t n3 = (i + 3 < G::CH) ? (((uint32_t)(j + 3) < th.n) ? th.u[(i + 3 < G::CH) ? i + 3 : 0] : 1u) : la[(i + 3 - G::CH) < 0 ? 0 : (i + 3 - G::CH)];
-            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-            const bool in4 = z && (f + ahead >= 4);
-            if (!in4) {
-                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-                zr += 2u + ((u > esc) ? 32u : rc);
-            } else if (n1 != 0) {  // last sample of a run of length f >= 4
-                zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
-                hasrun = 1;
-            }
-            // state after sample j -> k for sample j+1
-            P += u;
-            if (j >= 256u) W += sh.u[j - 256u] & 0x3FFFFFFFu;
-            F += ((th.kf[i] >> 8) & 1u) + (((th.kf[i] >> 9) & 1u) << 16);
-            if (j >= 96u) {
-                const uint32_t w = sh.u[j - 96u];
-                F96 += ((w >> 30) & 1u) + ((w >> 31) << 16);
-            }
-            const uint32_t c = j + 1u;
-            const uint32_t km = th.kf[i] & 0xFFu;
-            int bias = 0;
-            const uint64_t X = P + (c >> 1);
-            if (c > 256u && X >= c) {
-                const uint64_t L = ((P - W) + 128u) >> 8;
-                const uint64_t U = (3u * L + 3u) >> 2;
-                const uint64_t D = L + (L + 3u) / 3u + 1u;
-                if (X < U * c) {
-                    bias = 1;
-                } else if (X >= D * c) {
-                    bias = -1;
-                }
-            }
-            if (c >= 96u) {
-                const uint32_t d = F - F96;
-                const uint32_t large = d & 0xFFFFu, zero = d >> 16;
-                if (large * 4u >= 288u) {
-                    bias = (bias + 1 < 1) ? bias + 1 : 1;
-                } else if (zero * 5u >= 384u) {
-                    bias = (bias - 1 > -1) ? bias - 1 : -1;
-                }
-            }
-            int bk = (int)km + bias;
-            bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
-            kprev = (uint32_t)bk;
+    uint32_t w0 = (th.cnt > 0) ? sh.u[th.tid] : 0u;  // own sample incl. flags
+    uint32_t n1 = peek_u(sh, th.a + 1, n), n2 = peek_u(sh, th.a + 2, n), n3 = peek_u(sh, th.a + 3, n);
+    for (int i = 0; i < th.cnt; ++i) {
+        const uint32_t u = w0 & 0x3FFFFFFFu;
+        const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
+        rice += rc;
+        bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
+        const bool z = (u == 0);
+        f = z ? f + 1 : 0;
+        const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+        const bool in4 = z && (f + ahead >= 4);
+        if (!in4) {
+            const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+            zr += 2u + ((u > esc) ? 32u : rc);
+        } else if (n1 != 0) {  // last sample of a run of length f >= 4
+            zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
+            hasrun = 1;
         }
+        // state after this sample -> k for the next one
+        P += u;
+        ++c;
+        if (has256) W += sh.u[i * G::T + t - G::W256] & 0x3FFFFFFFu;
+        F += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
+        if (has96) {
+            const uint32_t w = sh.u[i * G::T + t - G::W96];
+            F96 += ((w >> 30) & 1u) + ((w >> 31) << 16);
+        }
+        kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+        // slide the lookahead window
+        w0 = sh.u[((i + 1 < G::CH) ? (i + 1) : 0) * G::T + t];
+        n1 = n2;
+        n2 = n3;
+        n3 = peek_u(sh, th.a + i + 4, n);
     }
     th.crice = rice;
     th.cbin = bin;
@@ -483,27 +520,25 @@ template <class G>
 LACX_HD void range_ksums(const Smem<G>& sh, uint32_t s, uint32_t e, uint64_t* A) {
     for (int k = 0; k < 16; ++k) A[k] = 0;
     const uint32_t gs = (s + 63u) >> 6, ge = e >> 6;
+    uint32_t e0 = e, s1 = e;  // direct ranges [s, e0) and [s1, e)
     if (gs < ge) {
         uint32_t C[30];
         for (int w = 0; w < 15; ++w) {
-            const uint32_t d = sh.grp[w][ge] - sh.grp[w][gs];
+            const uint32_t d = sh.xp.part.grp[w][ge] - sh.xp.part.grp[w][gs];
             C[w] = d & 0xFFFFu;
             C[w + 15] = d >> 16;
         }
         planes_to_ksums(C, A, 15);
-        for (uint32_t j = s; j < (gs << 6); ++j) {
-            const uint32_t u = sh.u[j];
-            for (int k = 0; k < 16; ++k) A[k] += u >> k;
-        }
-        for (uint32_t j = ge << 6; j < e; ++j) {
-            const uint32_t u = sh.u[j];
-            for (int k = 0; k < 16; ++k) A[k] += u >> k;
-        }
-    } else {
-        for (uint32_t j = s; j < e; ++j) {
-            const uint32_t u = sh.u[j];
-            for (int k = 0; k < 16; ++k) A[k] += u >> k;
-        }
+        e0 = gs << 6;
+        s1 = ge << 6;
+    }
+    for (uint32_t j = s; j < e0; ++j) {
+        const uint32_t u = sh.u[sw<G>((int)j)];
+        for (int k = 0; k < 16; ++k) A[k] += u >> k;
+    }
+    for (uint32_t j = s1; j < e; ++j) {
+        const uint32_t u = sh.u[sw<G>((int)j)];
+        for (int k = 0; k < 16; ++k) A[k] += u >> k;
     }
 }
 
@@ -527,14 +562,15 @@ LACX_HD void seg_static_eval(Smem<G>& sh, uint32_t n, int p, uint32_t part) {
     if (m != len) range_ksums(sh, s, s + m, A);
     si.ak = (uint8_t)pick_initial_k(A, m);
     for (int i = 0; i < 6; ++i) si.pad[i] = 0;
-    sh.seginfo[(2u << (p - 1)) - 2u + part] = si;
+    sh.xp.part.seginfo[(2u << (p - 1)) - 2u + part] = si;
 }
 
 // Stateless adaptive pass of one partition order over the thread's chunk
 // (ref block/encoder.cpp:201-263 with adapt_k_stateless :72-77).  Partial sums leave through `flush`.
-template <class G, class Flush>
+// sh.u holds the plain residual (no flag bits) in this phase.
+template <class G, bool NARROW, class Flush>
 LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush&& flush) {
-    if ((uint32_t)th.a >= th.n) return;
+    if (th.cnt <= 0) return;
     const uint32_t n = th.n;
     const uint32_t base = n >> p, parts = 1u << p;
     uint32_t part = (uint32_t)th.a / base;
@@ -547,53 +583,51 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
     {
         const uint32_t cs = s / G::CH;
         Pseg = sh.tabP[cs];
-        for (uint32_t j = cs * G::CH; j < s; ++j) Pseg += sh.u[j];
+        for (uint32_t j = cs * G::CH; j < s; ++j) Pseg += sh.u[sw<G>((int)j)];
     }
-    uint32_t la[3];
-    load_lookahead(th, sh, la);
     int32_t lastnz = sh.tabNZ[th.tid];
     if (lastnz < (int32_t)s - 1) lastnz = (int32_t)s - 1;
     int32_t f = th.a - 1 - lastnz;
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
+    uint32_t u = sh.u[th.tid];
+    uint32_t x1 = peek_u(sh, th.a + 1, n), x2 = peek_u(sh, th.a + 2, n), x3 = peek_u(sh, th.a + 3, n);
+    for (int i = 0; i < th.cnt; ++i) {
         const uint32_t j = (uint32_t)(th.a + i);
-        if (j < n) {
-            if (j == e) {  // partition boundary inside the chunk
-                flush(segbase + part, rice, bin, zr, hasrun);
-                rice = bin = zr = 0;
-                hasrun = 0;
-                ++part;
-                s = e;
-                e = (part + 1u == parts) ? n : s + base;
-                Pseg = P;
-                f = 0;
-            }
-            const uint32_t u = th.u[i];
-            const uint32_t kin = (j == s) ? (uint32_t)sh.seginfo[segbase + part].ak : kmean(P - Pseg, j - s);
-            const uint64_t rc = rice_cost(u, kin);
-            rice += rc;
-            bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
-            const bool z = (u == 0);
-            f = z ? f + 1 : 0;
-            const uint32_t x1 = (i + 1 < G::CH) ? th.u[(i + 1 < G::CH) ? i + 1 : 0] : la[(i + 1 - G::CH) < 0 ? 0 : (i + 1 - G::CH)];
-            const uint32_t x2 = (i + 2 < G::CH) ? th.u[(i + 2 < G::CH) ? i + 2 : 0] : la[(i + 2 - G::CH) < 0 ? 0 : (i + 2 - G::CH)];
-            const uint32_t x3 = (i + 3 < G::CH) ? th.u[(i + 3 < G::CH) ? i + 3 : 0] : la[(i + 3 - G::CH) < 0 ? 0 : (i + 3 - G::CH)];
-            const uint32_t n1 = (j + 1u < e) ? x1 : 1u;
-            const uint32_t n2 = (j + 2u < e) ? x2 : 1u;
-            const uint32_t n3 = (j + 3u < e) ? x3 : 1u;
-            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-            const bool in4 = z && (f + ahead >= 4);
-            if (!in4) {
-                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-                zr += 2u + ((u > esc) ? 32u : rc);
-            } else if (n1 != 0) {
-                zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
-                hasrun = 1;
-            }
-            P += u;
+        if (j == e) {  // partition boundary inside the chunk
+            flush(segbase + part, rice, bin, zr, hasrun);
+            rice = bin = zr = 0;
+            hasrun = 0;
+            ++part;
+            s = e;
+            e = (part + 1u == parts) ? n : s + base;
+            Pseg = P;
+            f = 0;
         }
+        const uint32_t kin = (j == s) ? (uint32_t)sh.xp.part.seginfo[segbase + part].ak
+                                      : kmean_t<NARROW>(P - Pseg, j - s);
+        const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
+        rice += rc;
+        bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
+        const bool z = (u == 0);
+        f = z ? f + 1 : 0;
+        const uint32_t n1 = (j + 1u < e) ? x1 : 1u;
+        const uint32_t n2 = (j + 2u < e) ? x2 : 1u;
+        const uint32_t n3 = (j + 3u < e) ? x3 : 1u;
+        const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+        const bool in4 = z && (f + ahead >= 4);
+        if (!in4) {
+            const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+            zr += 2u + ((u > esc) ? 32u : rc);
+        } else if (n1 != 0) {
+            zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
+            hasrun = 1;
+        }
+        P += u;
+        u = x1;
+        x1 = x2;
+        x2 = x3;
+        x3 = peek_u(sh, th.a + i + 4, n);
     }
     flush(segbase + part, rice, bin, zr, hasrun);
 }
@@ -601,10 +635,11 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
 // Mode choice of one partition (ref block/encoder.cpp:495-525); returns bits, writes (mode<<5)|k.
 template <class G>
 LACX_HD uint64_t seg_choose(Smem<G>& sh, uint32_t idx, int zero_run) {
-    const SegInfo si = sh.seginfo[idx];
-    const uint64_t normal = sh.segacc[idx][0], bin = sh.segacc[idx][1];
-    const bool allow_zr = zero_run && sh.segrun[idx] != 0;
-    const uint64_t zr = allow_zr ? sh.segacc[idx][2] : normal;
+    PartMem<G>& pm = sh.xp.part;
+    const SegInfo si = pm.seginfo[idx];
+    const uint64_t normal = pm.segacc[idx][0], bin = pm.segacc[idx][1];
+    const bool allow_zr = zero_run && pm.segrun[idx] != 0;
+    const uint64_t zr = allow_zr ? pm.segacc[idx][2] : normal;
     uint32_t mode = 0, k = si.ak;
     uint64_t bits = normal;
     if (allow_zr && zr < bits) {
@@ -620,7 +655,7 @@ LACX_HD uint64_t seg_choose(Smem<G>& sh, uint32_t idx, int zero_run) {
         k = si.sk;
         bits = si.sbits;
     }
-    sh.choice[idx] = (uint8_t)((mode << 5) | k);
+    pm.choice[idx] = (uint8_t)((mode << 5) | k);
     return bits;
 }
 
@@ -664,7 +699,7 @@ LACX_HD void finalize_plan(Smem<G>& sh, uint32_t n, int zero_run, int max_p, Cha
     best_total += (8u - (best_total & 7u)) & 7u;
     int best_p = 0;
     for (int p = 1; p <= max_p; ++p) {
-        uint64_t total = sh.pbits[p] + 8u + 7ull * (1u << p);
+        uint64_t total = sh.xp.part.pbits[p] + 8u + 7ull * (1u << p);
         total += (8u - (total & 7u)) & 7u;
         const uint64_t margin = best_total / 20u;
         if (total < best_total || (total <= best_total + margin && best_p == 0)) {
@@ -679,7 +714,7 @@ LACX_HD void finalize_plan(Smem<G>& sh, uint32_t n, int zero_run, int max_p, Cha
         out->part_mode_k[0] = (uint8_t)((mode << 5) | k);
     } else {
         const uint32_t parts = 1u << best_p, segbase = (2u << (best_p - 1)) - 2u;
-        for (uint32_t i = 0; i < parts; ++i) out->part_mode_k[i] = sh.choice[segbase + i];
+        for (uint32_t i = 0; i < parts; ++i) out->part_mode_k[i] = sh.xp.part.choice[segbase + i];
     }
 }
 

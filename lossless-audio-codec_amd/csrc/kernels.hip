@@ -429,7 +429,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     const SlotSrc src = slot_src(L, R, slot & 3);
 
     Thread<G> th;
-    load_chunk(th, src, g.start, n, tid);
+    thread_init(th, n, tid);
+    stage_samples(th, sh, src, g.start);
     for (int i = tid; i < (int)(sizeof(LpcSet) / 2); i += G::T)
         reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(&lpcs[sidx])[i];
     if (tid < 32) {
@@ -454,8 +455,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
             for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
         }
-        residual_chunk(th, cand, sh.lpc);
-        phase_r(th, sh);
+        phase_r(th, sh, cand);
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
         plane_totals_wave(th, pt, pt256, tid);
@@ -463,14 +463,23 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         scan_pz_part2(sh, tid, sr);
         if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
         __syncthreads();  // B2
-        phase_a(th, sh);
+        const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
+        if (narrow) {
+            phase_a<G, true>(th, sh);
+        } else {
+            phase_a<G, false>(th, sh);
+        }
         uint32_t fown;
         const uint32_t finc = scan_f_part1(sh, tid, fown);
         __syncthreads();  // B3
         scan_f_part2(sh, tid, finc, fown);
         __syncthreads();  // B4
         const uint32_t k0 = sh.cur_k0;
-        phase_b(th, sh, k0);
+        if (narrow) {
+            phase_b<G, true>(th, sh, k0);
+        } else {
+            phase_b<G, false>(th, sh, k0);
+        }
         {
             const bool active = (uint32_t)th.a < n;
             const uint64_t r0 = wave_sum_u64(active ? th.crice : 0ull);
@@ -494,37 +503,38 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
 
     // ---- partition search on the winning residual -------------------------------------------
     const int best = sh.best_cand;
-    residual_chunk(th, best, sh.lpc);
-    phase_r(th, sh);
-    store_u_plain(th, sh);
+    phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
     int max_p = 0;
     if (prm.partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
     const int nseg = max_p > 0 ? ((2 << max_p) - 2) : 0;
-    for (int i = tid; i < 15 * (G::NG + 1); i += G::T) (&sh.grp[0][0])[i] = 0;
-    for (int i = tid; i < nseg; i += G::T) {
-        sh.segacc[i][0] = sh.segacc[i][1] = sh.segacc[i][2] = 0;
-        sh.segrun[i] = 0;
-    }
-    if (tid <= G::MAXP) sh.pbits[tid] = 0;
+    PartMem<G>& pm = sh.xp.part;
     {
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
         __syncthreads();
+        // the partition scratch aliases the samples: clear it only now that every thread is past phase_r
+        for (int i = tid; i < 15 * (G::NG + 1); i += G::T) (&pm.grp[0][0])[i] = 0;
+        for (int i = tid; i < nseg; i += G::T) {
+            pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
+            pm.segrun[i] = 0;
+        }
+        if (tid <= G::MAXP) pm.pbits[tid] = 0;
         scan_pz_part2(sh, tid, sr);
         __syncthreads();
     }
+    const bool pnarrow = sh.tabP[G::T] < (1ull << 31);
     if (max_p > 0) {
         {
             uint32_t words[15];
             packed_planes(th, words);
 #pragma unroll
-            for (int w = 0; w < 15; ++w) atomicAdd(&sh.grp[w][tid / G::TPG], words[w]);
+            for (int w = 0; w < 15; ++w) atomicAdd(&pm.grp[w][tid / G::TPG], words[w]);
         }
         __syncthreads();
         {
             constexpr int NW = G::T / 64;
             const int wave = tid >> 6, lane = tid & 63;
-            for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(sh.grp[w], G::NG + 1, lane);
+            for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(pm.grp[w], G::NG + 1, lane);
         }
         __syncthreads();
         for (int idx = tid; idx < nseg; idx += G::T) {
@@ -532,21 +542,25 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
         }
         __syncthreads();
+        auto flush = [&pm](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
+                           uint32_t hr) {
+            atomicAdd(&pm.segacc[idx][0], rc);
+            atomicAdd(&pm.segacc[idx][1], bn);
+            atomicAdd(&pm.segacc[idx][2], zr);
+            if (hr) atomicOr(&pm.segrun[idx], 1u);
+        };
         for (int p = 1; p <= max_p; ++p) {
-            partition_pass(th, sh, p,
-                           [&sh](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
-                                 uint32_t hr) {
-                               atomicAdd(&sh.segacc[idx][0], rc);
-                               atomicAdd(&sh.segacc[idx][1], bn);
-                               atomicAdd(&sh.segacc[idx][2], zr);
-                               if (hr) atomicOr(&sh.segrun[idx], 1u);
-                           });
+            if (pnarrow) {
+                partition_pass<G, true>(th, sh, p, flush);
+            } else {
+                partition_pass<G, false>(th, sh, p, flush);
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < nseg; idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             const unsigned long long bits = seg_choose(sh, (uint32_t)idx, prm.zero_run);
-            atomicAdd(&sh.pbits[p], bits);
+            atomicAdd(&pm.pbits[p], bits);
         }
         __syncthreads();
     }

@@ -56,14 +56,17 @@ void plane_totals(Smem<G>& sh, const std::vector<Thread<G>>& th) {
 }
 
 template <class G>
-int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, ChannelPlan* out) {
+int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int force_wide, ChannelPlan* out) {
     if (n == 0 || n > (uint32_t)G::MAXN) return 1;
     Smem<G>* shp = new Smem<G>;
     Smem<G>& sh = *shp;
     std::memset(shp, 0, sizeof(Smem<G>));
     std::vector<Thread<G>> th(G::T);
     SlotSrc src{x, nullptr, CH_L};
-    for (int t = 0; t < G::T; ++t) load_chunk(th[t], src, 0, n, t);
+    for (int t = 0; t < G::T; ++t) {
+        thread_init(th[t], n, t);
+        stage_samples(th[t], sh, src, 0);
+    }
     int64_t r[13];
     autocorr13(x, n, r);
     const int max_valid_order = (n > 1) ? (int)((n - 1 < 32u) ? n - 1 : 32u) : 0;
@@ -71,14 +74,14 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, Channe
     sh.best_cand = -1;
     for (int cand = 0; cand <= 10; ++cand) {
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;
-        for (int t = 0; t < G::T; ++t) {
-            residual_chunk(th[t], cand, sh.lpc);
-            phase_r(th[t], sh);
-        }
+        for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, cand);
         scans_after_r(sh);
         plane_totals(sh, th);
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
-        for (int t = 0; t < G::T; ++t) phase_a(th[t], sh);
+        const bool narrow = !force_wide && sh.tabP[G::T] < (1ull << 31);
+        for (int t = 0; t < G::T; ++t) {
+            if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
+        }
         {
             uint32_t run = 0;
             for (int t = 0; t < G::T; ++t) {
@@ -90,7 +93,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, Channe
         }
         sh.acc[0][0] = sh.acc[0][1] = sh.acc[0][2] = sh.acc[0][3] = 0;
         for (int t = 0; t < G::T; ++t) {
-            phase_b(th[t], sh, k0);
+            if (narrow) phase_b<G, true>(th[t], sh, k0); else phase_b<G, false>(th[t], sh, k0);
             if ((uint32_t)th[t].a < n) {
                 sh.acc[0][0] += th[t].crice;
                 sh.acc[0][1] += th[t].cbin;
@@ -102,52 +105,50 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, Channe
     }
     // partition search on the winner
     const int best = sh.best_cand;
-    for (int t = 0; t < G::T; ++t) {
-        residual_chunk(th[t], best, sh.lpc);
-        phase_r(th[t], sh);
-        store_u_plain(th[t], sh);
-    }
+    for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, best);
     scans_after_r(sh);
+    const bool pnarrow = !force_wide && sh.tabP[G::T] < (1ull << 31);
+    PartMem<G>& pm = sh.xp.part;
     int max_p = 0;
     if (partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
     if (max_p > 0) {
         for (int w = 0; w < 15; ++w)
-            for (int g = 0; g <= G::NG; ++g) sh.grp[w][g] = 0;
+            for (int g = 0; g <= G::NG; ++g) pm.grp[w][g] = 0;
         for (int t = 0; t < G::T; ++t) {
             uint32_t words[15];
             packed_planes(th[t], words);
-            for (int w = 0; w < 15; ++w) sh.grp[w][t / G::TPG] += words[w];
+            for (int w = 0; w < 15; ++w) pm.grp[w][t / G::TPG] += words[w];
         }
         for (int w = 0; w < 15; ++w) {
             uint32_t run = 0;
             for (int g = 0; g <= G::NG; ++g) {
-                const uint32_t v = sh.grp[w][g];
-                sh.grp[w][g] = run;
+                const uint32_t v = pm.grp[w][g];
+                pm.grp[w][g] = run;
                 run += v;
             }
         }
         for (int p = 1; p <= max_p; ++p)
             for (uint32_t part = 0; part < (1u << p); ++part) seg_static_eval(sh, n, p, part);
         for (int i = 0; i < G::NSEG; ++i) {
-            sh.segacc[i][0] = sh.segacc[i][1] = sh.segacc[i][2] = 0;
-            sh.segrun[i] = 0;
+            pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
+            pm.segrun[i] = 0;
         }
         for (int t = 0; t < G::T; ++t) {
             for (int p = 1; p <= max_p; ++p) {
-                partition_pass(th[t], sh, p,
-                               [&](uint32_t idx, unsigned long long rc, unsigned long long bn,
-                                   unsigned long long zr, uint32_t hr) {
-                                   sh.segacc[idx][0] += rc;
-                                   sh.segacc[idx][1] += bn;
-                                   sh.segacc[idx][2] += zr;
-                                   sh.segrun[idx] |= hr;
-                               });
+                auto flush = [&](uint32_t idx, unsigned long long rc, unsigned long long bn,
+                                 unsigned long long zr, uint32_t hr) {
+                    pm.segacc[idx][0] += rc;
+                    pm.segacc[idx][1] += bn;
+                    pm.segacc[idx][2] += zr;
+                    pm.segrun[idx] |= hr;
+                };
+                if (pnarrow) partition_pass<G, true>(th[t], sh, p, flush); else partition_pass<G, false>(th[t], sh, p, flush);
             }
         }
         for (int p = 1; p <= max_p; ++p) {
-            sh.pbits[p] = 0;
+            pm.pbits[p] = 0;
             const uint32_t segbase = (2u << (p - 1)) - 2u;
-            for (uint32_t part = 0; part < (1u << p); ++part) sh.pbits[p] += seg_choose(sh, segbase + part, zero_run);
+            for (uint32_t part = 0; part < (1u << p); ++part) pm.pbits[p] += seg_choose(sh, segbase + part, zero_run);
         }
     }
     std::memset(out, 0, sizeof(*out));
@@ -161,9 +162,11 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, Channe
 extern "C" {
 
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
-int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, ChannelPlan* out) {
-    if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, out);
-    return run_sim<Geo<4, 64>>(x, n, zero_run, partitioning, out);
+// force_wide: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken
+int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
+                   ChannelPlan* out) {
+    if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);
+    return run_sim<Geo<4, 64>>(x, n, zero_run, partitioning, force_wide, out);
 }
 
 // kmean() against the division it replaces; returns the number of mismatches.
