@@ -118,29 +118,36 @@ __device__ __forceinline__ void scan_f_part2(Smem<G>& sh, int tid, uint32_t inc,
     if (tid == G::T - 1) sh.tabF[G::T] = base + inc;
 }
 
-// Per-plane population counts of the wave's bit-sliced chunk counters, via ballots; lanes 0..29 then
-// add their plane's count to the block totals.
+// Per-plane population counts of the wave's bit-sliced chunk counters, via ballots.  Ballot masks and
+// their popcounts are wave-uniform, so the per-plane totals accumulate on the scalar unit; planes above
+// the highest set bit in the wave are skipped.  Lanes 0..29 then add their plane's count to the block totals.
 template <class G>
 __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t* planeTot, uint32_t* planeTot256,
                                                   int tid) {
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t mine = 0, mine256 = 0;
+    uint32_t any = 0;
+#pragma unroll
+    for (int l = 0; l < G::LV; ++l) any |= th.cs[l];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) any |= (uint32_t)__shfl_xor((int)any, d, 64);
+    const int nplanes = 32 - __clz((int)__builtin_amdgcn_readfirstlane((int)any));  // uniform, 0..30
     // lanes of wave 0 whose chunk lies inside the first 256 samples
     const uint64_t m256 = (G::W256 >= 64) ? ~0ull : ((1ull << (G::W256 & 63)) - 1ull);
+    uint32_t mine = 0, mine256 = 0;
+    for (int b = 0; b < nplanes; ++b) {
+        uint32_t tot = 0, tot256 = 0;
 #pragma unroll
-    for (int l = 0; l < G::LV; ++l) {
-        const uint32_t c = th.cs[l];
-        for (int b = 0; b < 30; ++b) {
-            const uint64_t m = __ballot((c >> b) & 1u);
-            const uint32_t cnt = (uint32_t)__popcll(m) << l;
-            const uint32_t cnt256 = (uint32_t)__popcll(m & m256) << l;
-            if (lane == b) {
-                mine += cnt;
-                mine256 += cnt256;
-            }
+        for (int l = 0; l < G::LV; ++l) {
+            const uint64_t m = __ballot((th.cs[l] >> b) & 1u);
+            tot += (uint32_t)__popcll(m) << l;
+            tot256 += (uint32_t)__popcll(m & m256) << l;
+        }
+        if (lane == b) {
+            mine = tot;
+            mine256 = tot256;
         }
     }
-    if (lane < 30) {
+    if (lane < nplanes) {
         atomicAdd(&planeTot[lane], mine);
         if (wave == 0) atomicAdd(&planeTot256[lane], mine256);
     }
@@ -446,6 +453,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     int parity = 0;
     for (int cand = 0; cand <= 10; ++cand) {
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
+        if (cand >= 6 && (prm.debug_skip & 16u)) continue;
+        if (cand >= 1 && (prm.debug_skip & 64u)) continue;
         uint32_t* pt = sh.planeTot[parity];
         uint32_t* pt256 = sh.planeTot256[parity];
         unsigned long long* acc = sh.acc[parity];
@@ -458,13 +467,15 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         phase_r(th, sh, cand);
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
-        plane_totals_wave(th, pt, pt256, tid);
+        if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
         __syncthreads();  // B1
         scan_pz_part2(sh, tid, sr);
         if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
         __syncthreads();  // B2
         const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
-        if (narrow) {
+        if (prm.debug_skip & 2u) {
+            sh.tabF[tid] = 0;
+        } else if (narrow) {
             phase_a<G, true>(th, sh);
         } else {
             phase_a<G, false>(th, sh);
@@ -475,7 +486,10 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         scan_f_part2(sh, tid, finc, fown);
         __syncthreads();  // B4
         const uint32_t k0 = sh.cur_k0;
-        if (narrow) {
+        if (prm.debug_skip & 4u) {
+            th.crice = th.cbin = th.czr = 1;
+            th.chasrun = 0;
+        } else if (narrow) {
             phase_b<G, true>(th, sh, k0);
         } else {
             phase_b<G, false>(th, sh, k0);
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(pm.grp[w], G::NG + 1, lane);
         }
         __syncthreads();
-        for (int idx = tid; idx < nseg; idx += G::T) {
+        for (int idx = tid; idx < ((prm.debug_skip & 32u) ? 0 : nseg); idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
         }
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             atomicAdd(&pm.segacc[idx][2], zr);
             if (hr) atomicOr(&pm.segrun[idx], 1u);
         };
-        for (int p = 1; p <= max_p; ++p) {
+        for (int p = 1; p <= ((prm.debug_skip & 8u) ? 0 : max_p); ++p) {
             if (pnarrow) {
                 partition_pass<G, true>(th, sh, p, flush);
             } else {

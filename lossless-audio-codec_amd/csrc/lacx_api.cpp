@@ -158,6 +158,10 @@ int analyze_on_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_r
     prm.bit_depth = bit_depth;
     prm.zero_run = e->cfg.zero_run_enabled ? 1 : 0;
     prm.partitioning = e->cfg.partitioning_enabled ? 1 : 0;
+    {
+        const char* dbg = std::getenv("LACX_DEBUG_SKIP");  // timing ablations only
+        prm.debug_skip = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
+    }
     HIP_TRY(e, launch_analysis(d_left, d_right, prm, e->ws, stream, e->ev), "kernel launch");
     const auto t0 = clk::now();
     HIP_TRY(e, hipMemcpyAsync(e->h_plans, e->ws.plans, (size_t)nb * kSlotsPerBlock * sizeof(ChannelPlan),

@@ -59,6 +59,7 @@ struct AnalyzeParams {
     int32_t bit_depth;     // 16 / 24 (range validation); 0 = no validation (Block::Encoder path)
     int32_t zero_run;
     int32_t partitioning;
+    uint32_t debug_skip;   // diagnostic ablation mask (timing experiments only; 0 in production)
 };
 
 }  // namespace lacx
