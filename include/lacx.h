@@ -140,6 +140,10 @@ int lacx_block_plan_only(lacx_encoder* enc, const int32_t* pcm, uint32_t n, lacx
 int lacx_debug_lpc(lacx_encoder* enc, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
                    uint8_t* used);
 
+/* Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums of k_analyze<16,1024>; returns 0 in
+ * production builds. out32[24] = number of waves accumulated. */
+int lacx_debug_stamps(unsigned long long* out32);
+
 /* Number of visible HIP devices (0 when the runtime or a GPU is missing); does not initialise one. */
 int lacx_device_count(void);
 

@@ -112,42 +112,31 @@ LACX_HD uint64_t rice_cost(uint32_t u, uint32_t k) {  // ref block/encoder.cpp:6
 //   3L > 4 mean  <=>  X < ceil(3L/4) * c          4L+3 < 3 mean  <=>  X >= (floor((4L+3)/3) + 1) * c
 template <bool NARROW>
 LACX_HD uint32_t biased_k(uint32_t km, uint64_t P, uint64_t W, uint32_t d, uint32_t c) {
-    int bias = 0;
-    if (c > 256u) {
-        if (NARROW) {
-            const uint32_t X = (uint32_t)P + (c >> 1);
-            const uint32_t L = (((uint32_t)P - (uint32_t)W) + 128u) >> 8;
-            const uint32_t U = (3u * L + 3u) >> 2;
-            const uint32_t D = L + (L + 3u) / 3u + 1u;
-            if (X >= c) {
-                if ((uint64_t)X < (uint64_t)U * c) {
-                    bias = 1;
-                } else if ((uint64_t)X >= (uint64_t)D * c) {
-                    bias = -1;
-                }
-            }
-        } else {
-            const uint64_t X = P + (c >> 1);
-            const uint64_t L = ((P - W) + 128u) >> 8;
-            const uint64_t U = (3u * L + 3u) >> 2;
-            const uint64_t D = L + (L + 3u) / 3u + 1u;
-            if (X >= c) {
-                if (X < U * c) {
-                    bias = 1;
-                } else if (X >= D * c) {
-                    bias = -1;
-                }
-            }
-        }
+    // local mean of the last 256 (ref rice.hpp:85-87); u < 2^30 keeps L, U, D inside 32 bits
+    const uint32_t L = NARROW ? ((((uint32_t)P - (uint32_t)W) + 128u) >> 8) : (uint32_t)(((P - W) + 128u) >> 8);
+    const uint32_t U = (3u * L + 3u) >> 2;
+    const uint32_t D = L + (L + 3u) / 3u + 1u;
+    bool up, dn;
+    if (NARROW) {
+        const uint32_t X = (uint32_t)P + (c >> 1);
+        const bool act = (c > 256u) & (X >= c);
+        up = act & ((uint64_t)X < (uint64_t)U * c);
+        dn = act & ((uint64_t)X >= (uint64_t)D * c);
+    } else {
+        const uint64_t X = P + (c >> 1);
+        const bool act = (c > 256u) & (X >= c);
+        up = act & (X < (uint64_t)U * c);
+        dn = act & (X >= (uint64_t)D * c);
     }
-    if (c >= 96u) {
-        const uint32_t large = d & 0xFFFFu, zero = d >> 16;
-        if (large * 4u >= 288u) {
-            bias = (bias + 1 < 1) ? bias + 1 : 1;
-        } else if (zero * 5u >= 384u) {
-            bias = (bias - 1 > -1) ? bias - 1 : -1;
-        }
-    }
+    int bias = up ? 1 : (dn ? -1 : 0);
+    // micro window (ref rice.hpp:97-105): large*4 >= 96*3 <=> large >= 72 ; zero*5 >= 96*4 <=> zero >= 77
+    const uint32_t large = d & 0xFFFFu, zero = d >> 16;
+    const bool m = c >= 96u;
+    const bool big = m & (large >= 72u);
+    const bool sml = m & (zero >= 77u) & !big;
+    const int bp = bias + 1 < 1 ? bias + 1 : 1;
+    const int bm = bias - 1 > -1 ? bias - 1 : -1;
+    bias = big ? bp : (sml ? bm : bias);
     int bk = (int)km + bias;
     bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
     return (uint32_t)bk;
@@ -390,11 +379,12 @@ LACX_HD void phase_a(Thread<G>& th, Smem<G>& sh) {
 }
 
 // Sample j as seen by the zero-run lookahead: its u, or 1 ("not a zero") at/after `limit`.
+// j may run up to 3 past the slot; the read then lands in the words that follow u[] and is discarded.
 template <class G>
-LACX_HD uint32_t peek_u(const Smem<G>& sh, int j, uint32_t limit) {
-    const int jj = ((uint32_t)j < limit) ? j : 0;
-    const uint32_t v = sh.u[sw<G>(jj)] & 0x3FFFFFFFu;
-    return ((uint32_t)j < limit) ? v : 1u;
+LACX_HD uint32_t peek_u(const Smem<G>& sh, uint32_t j, uint32_t limit) {
+    const uint32_t idx = (j % (uint32_t)G::CH) * (uint32_t)G::T + (j / (uint32_t)G::CH);
+    const uint32_t v = sh.u[idx] & 0x3FFFFFFFu;
+    return (j < limit) ? v : 1u;
 }
 
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
@@ -407,7 +397,10 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     uint64_t W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;    // P_{a-1-256}
     uint32_t F = sh.tabF[t];                                   // flag counts over [0, a-1]
     uint32_t F96 = (t >= G::W96) ? sh.tabF[t - G::W96] : 0;    // ... over [0, a-1-96]
-    const bool has256 = t >= G::W256, has96 = t >= G::W96;
+    const uint32_t m256 = (t >= G::W256) ? 0x3FFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
+    const uint32_t m96 = (t >= G::W96) ? 0xFFFFFFFFu : 0u;
+    const int t256 = (t >= G::W256) ? t - G::W256 : t;
+    const int t96 = (t >= G::W96) ? t - G::W96 : t;
     uint32_t c = (uint32_t)th.a;
     // k in force for the first sample of the chunk: the value returned after sample a-1
     uint32_t kin = k0;
@@ -415,9 +408,12 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
-    uint32_t w0 = (th.cnt > 0) ? sh.u[th.tid] : 0u;  // own sample incl. flags
-    uint32_t n1 = peek_u(sh, th.a + 1, n), n2 = peek_u(sh, th.a + 2, n), n3 = peek_u(sh, th.a + 3, n);
-    for (int i = 0; i < th.cnt; ++i) {
+    uint32_t w0 = sh.u[t];  // own sample incl. flags
+    uint32_t n1 = peek_u(sh, (uint32_t)th.a + 1u, n), n2 = peek_u(sh, (uint32_t)th.a + 2u, n),
+             n3 = peek_u(sh, (uint32_t)th.a + 3u, n);
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        if (i >= th.cnt) break;
         const uint32_t u = w0 & 0x3FFFFFFFu;
         const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
         rice += rc;
@@ -425,29 +421,26 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         const bool z = (u == 0);
         f = z ? f + 1 : 0;
         const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-        const bool in4 = z && (f + ahead >= 4);
-        if (!in4) {
-            const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-            zr += 2u + ((u > esc) ? 32u : rc);
-        } else if (n1 != 0) {  // last sample of a run of length f >= 4
-            zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
-            hasrun = 1;
-        }
+        const bool in4 = z & (f + ahead >= 4);
+        const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+        const uint32_t plain = 2u + ((u > esc) ? 32u : rc);              // not inside a run of >= 4
+        const uint32_t token = 5u + (((uint32_t)(f - 4)) >> 2);          // last sample of such a run
+        const bool runend = in4 & (n1 != 0);
+        zr += in4 ? (runend ? token : 0u) : plain;
+        hasrun |= runend ? 1u : 0u;
         // state after this sample -> k for the next one
         P += u;
         ++c;
-        if (has256) W += sh.u[i * G::T + t - G::W256] & 0x3FFFFFFFu;
+        W += sh.u[i * G::T + t256] & m256;
         F += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
-        if (has96) {
-            const uint32_t w = sh.u[i * G::T + t - G::W96];
-            F96 += ((w >> 30) & 1u) + ((w >> 31) << 16);
-        }
+        const uint32_t w96 = sh.u[i * G::T + t96] & m96;
+        F96 += ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
         kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
         // slide the lookahead window
-        w0 = sh.u[((i + 1 < G::CH) ? (i + 1) : 0) * G::T + t];
+        w0 = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
         n1 = n2;
         n2 = n3;
-        n3 = peek_u(sh, th.a + i + 4, n);
+        n3 = peek_u(sh, (uint32_t)(th.a + i) + 4u, n);
     }
     th.crice = rice;
     th.cbin = bin;
@@ -591,7 +584,8 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
     uint32_t u = sh.u[th.tid];
-    uint32_t x1 = peek_u(sh, th.a + 1, n), x2 = peek_u(sh, th.a + 2, n), x3 = peek_u(sh, th.a + 3, n);
+    uint32_t x1 = peek_u(sh, (uint32_t)th.a + 1u, n), x2 = peek_u(sh, (uint32_t)th.a + 2u, n),
+             x3 = peek_u(sh, (uint32_t)th.a + 3u, n);
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t j = (uint32_t)(th.a + i);
         if (j == e) {  // partition boundary inside the chunk
@@ -627,9 +621,88 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
         u = x1;
         x1 = x2;
         x2 = x3;
-        x3 = peek_u(sh, th.a + i + 4, n);
+        x3 = peek_u(sh, (uint32_t)(th.a + i) + 4u, n);
     }
     flush(segbase + part, rice, bin, zr, hasrun);
+}
+
+
+// True when every partition boundary of every order 1..max_p falls on a chunk boundary, i.e. each
+// thread's chunk lies inside exactly one partition of each order (all 16384-sample blocks and the
+// 256-sample probes).  The fused pass below then evaluates all orders in one walk over the chunk.
+template <class G>
+LACX_HD bool partitions_chunk_aligned(uint32_t n, int max_p) {
+    return max_p > 0 && (n % ((uint32_t)G::CH << max_p)) == 0u;
+}
+
+// All partition orders in one pass (32-bit arithmetic: requires total sum of u < 2^31).
+// Same numbers as partition_pass<G, true> run for p = 1..max_p.
+template <class G, class Flush>
+LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, Flush&& flush) {
+    if (th.cnt <= 0) return;
+    const uint32_t n = th.n;
+    const int t = th.tid;
+    const uint32_t a = (uint32_t)th.a;
+    const uint32_t Pa = (uint32_t)sh.tabP[t];  // P_{a-1}
+    uint32_t s[G::MAXP], rem[G::MAXP], Pseg[G::MAXP], ak[G::MAXP], sidx[G::MAXP];
+    uint32_t rice[G::MAXP], bin[G::MAXP], zr[G::MAXP];
+    uint32_t hasrun = 0;  // bit p-1
+#pragma unroll
+    for (int q = 0; q < G::MAXP; ++q) {
+        const int p = q + 1;
+        rice[q] = bin[q] = zr[q] = 0;
+        s[q] = rem[q] = Pseg[q] = ak[q] = sidx[q] = 0;
+        if (p <= max_p) {
+            const uint32_t base = n >> p;
+            const uint32_t part = a / base;
+            s[q] = part * base;
+            rem[q] = s[q] + base - a;  // samples from a to the end of the partition
+            Pseg[q] = (uint32_t)sh.tabP[s[q] / (uint32_t)G::CH];
+            sidx[q] = (2u << (p - 1)) - 2u + part;
+            ak[q] = sh.xp.part.seginfo[sidx[q]].ak;
+        }
+    }
+    int32_t fg = (int32_t)a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk (not yet clipped to a partition)
+    uint32_t P = Pa;
+    uint32_t u = sh.u[t];
+    uint32_t x1 = peek_u(sh, a + 1u, n), x2 = peek_u(sh, a + 2u, n), x3 = peek_u(sh, a + 3u, n);
+    for (int i = 0; i < th.cnt; ++i) {
+        const uint32_t j = a + (uint32_t)i;
+        const bool z = (u == 0);
+        fg = z ? fg + 1 : 0;
+        const uint32_t ahead_g = (x1 != 0) ? 0u : ((x2 != 0) ? 1u : ((x3 != 0) ? 2u : 3u));
+        const uint32_t small = (u == 0) ? 2u : 3u;
+        const bool is_small = u <= 4u;
+#pragma unroll
+        for (int q = 0; q < G::MAXP; ++q) {
+            if (q < max_p) {
+                const uint32_t cbefore = j - s[q];                       // samples of the partition before j
+                const uint32_t kin = (cbefore == 0) ? ak[q] : kmean32(P - Pseg[q], cbefore);
+                const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
+                rice[q] += rc;
+                bin[q] += is_small ? small : 2u + rc;
+                const uint32_t left = rem[q] - 1u - (uint32_t)i;          // samples after j inside the partition
+                const uint32_t fp = ((uint32_t)fg < cbefore + 1u) ? (uint32_t)fg : cbefore + 1u;
+                const uint32_t ahead = ahead_g < left ? ahead_g : left;
+                const bool in4 = z & (fp + ahead >= 4u);
+                const bool runend = in4 & (ahead == 0u);
+                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+                const uint32_t plain = 2u + ((u > esc) ? 32u : rc);
+                const uint32_t token = 5u + ((fp - 4u) >> 2);
+                zr[q] += in4 ? (runend ? token : 0u) : plain;
+                hasrun |= runend ? (1u << q) : 0u;
+            }
+        }
+        P += u;
+        u = x1;
+        x1 = x2;
+        x2 = x3;
+        x3 = peek_u(sh, j + 4u, n);
+    }
+#pragma unroll
+    for (int q = 0; q < G::MAXP; ++q) {
+        if (q < max_p) flush(sidx[q], rice[q], bin[q], zr[q], (hasrun >> q) & 1u);
+    }
 }
 
 // Mode choice of one partition (ref block/encoder.cpp:495-525); returns bits, writes (mode<<5)|k.

@@ -23,6 +23,8 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
                            const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev);
 
 size_t analyze_smem_bytes_full();
+// Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.
+int debug_read_stamps(unsigned long long* out32);
 size_t analyze_smem_bytes_probe();
 
 }  // namespace lacx

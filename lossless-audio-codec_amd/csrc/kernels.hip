@@ -19,6 +19,19 @@
 
 namespace lacx {
 
+// Diagnostic phase stamps (only in builds made with -DLACX_STAMPS; the production kernel has none).
+#ifdef LACX_STAMPS
+__device__ unsigned long long g_stamp_acc[32];
+#define STAMP(k)                                                        \
+    do {                                                                \
+        const unsigned long long _now = __builtin_amdgcn_s_memtime();   \
+        stamp_acc[k] += _now - stamp_prev;                              \
+        stamp_prev = _now;                                              \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
@@ -412,29 +425,49 @@ __global__ __launch_bounds__(64) void k_levinson(AnalyzeParams prm, const int64_
 // ---------------------------------------------------------------------------------------------
 template <class G>
 __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
-                                                  AnalyzeParams prm, int probe_class,
-                                                  const LpcSet* __restrict__ lpcs,
+                                                  AnalyzeParams prm, int probe_class, uint32_t blk_offset,
+                                                  int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
     const int tid = threadIdx.x;
+    // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
+    // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
+    // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
     uint32_t blk;
-    int slot;
+    int slot = -1;
     if (probe_class) {
         blk = blockIdx.x / 12u;
-        slot = 4 + (int)(blockIdx.x % 12u);
+        const int s = 4 + (int)(blockIdx.x % 12u);
+        if ((need[blk] >> s) & 1u) slot = s;
     } else {
-        const uint32_t per = prm.channels == 2 ? 4u : 1u;
-        blk = blockIdx.x / per;
-        slot = (int)(blockIdx.x % per);
+        const uint32_t per = prm.channels == 2 ? 2u : 1u;
+        blk = blk_offset + blockIdx.x / per;
+        int which = (int)(blockIdx.x % per) + which_base;
+        uint32_t m = need[blk] & 0xFu;
+        while (m) {
+            const int s = __ffs((int)m) - 1;
+            if (which == 0) {
+                slot = s;
+                break;
+            }
+            --which;
+            m &= m - 1u;
+        }
     }
-    if (!((need[blk] >> slot) & 1u)) return;  // uniform for the workgroup
+    if (slot < 0) return;  // uniform for the workgroup
     const SlotGeom g = slot_geom(prm, blk, slot);
     const uint32_t n = g.n;
     const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
     const SlotSrc src = slot_src(L, R, slot & 3);
 
+#ifdef LACX_STAMPS
+    unsigned long long stamp_acc[24];
+    for (int k = 0; k < 24; ++k) stamp_acc[k] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     Thread<G> th;
     thread_init(th, n, tid);
     stage_samples(th, sh, src, g.start);
@@ -447,6 +480,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
     if (tid == 0) sh.best_cand = -1;
     __syncthreads();
+    STAMP(0);
 
     int pending = -1;        // candidate whose totals thread 0 still has to score
     uint32_t pending_k0 = 0;
@@ -464,14 +498,21 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
             for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
         }
+        STAMP(1);
         phase_r(th, sh, cand);
+        STAMP(2);
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
+        STAMP(3);
         if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
+        STAMP(4);
         __syncthreads();  // B1
+        STAMP(5);
         scan_pz_part2(sh, tid, sr);
         if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
+        STAMP(6);
         __syncthreads();  // B2
+        STAMP(7);
         const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
         if (prm.debug_skip & 2u) {
             sh.tabF[tid] = 0;
@@ -480,11 +521,15 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         } else {
             phase_a<G, false>(th, sh);
         }
+        STAMP(8);
         uint32_t fown;
         const uint32_t finc = scan_f_part1(sh, tid, fown);
+        STAMP(9);
         __syncthreads();  // B3
+        STAMP(10);
         scan_f_part2(sh, tid, finc, fown);
         __syncthreads();  // B4
+        STAMP(11);
         const uint32_t k0 = sh.cur_k0;
         if (prm.debug_skip & 4u) {
             th.crice = th.cbin = th.czr = 1;
@@ -494,6 +539,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         } else {
             phase_b<G, false>(th, sh, k0);
         }
+        STAMP(12);
         {
             const bool active = (uint32_t)th.a < n;
             const uint64_t r0 = wave_sum_u64(active ? th.crice : 0ull);
@@ -507,7 +553,9 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
                 atomicAdd(&acc[3], (unsigned long long)r3);
             }
         }
+        STAMP(13);
         __syncthreads();  // B5
+        STAMP(14);
         pending = cand;
         pending_k0 = k0;
         parity ^= 1;
@@ -515,6 +563,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     if (tid == 0) score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
     __syncthreads();
 
+    STAMP(15);
     // ---- partition search on the winning residual -------------------------------------------
     const int best = sh.best_cand;
     phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
@@ -537,6 +586,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         __syncthreads();
     }
     const bool pnarrow = sh.tabP[G::T] < (1ull << 31);
+    STAMP(16);
     if (max_p > 0) {
         {
             uint32_t words[15];
@@ -551,11 +601,13 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(pm.grp[w], G::NG + 1, lane);
         }
         __syncthreads();
+        STAMP(17);
         for (int idx = tid; idx < ((prm.debug_skip & 32u) ? 0 : nseg); idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
         }
         __syncthreads();
+        STAMP(18);
         auto flush = [&pm](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
                            uint32_t hr) {
             atomicAdd(&pm.segacc[idx][0], rc);
@@ -563,14 +615,22 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             atomicAdd(&pm.segacc[idx][2], zr);
             if (hr) atomicOr(&pm.segrun[idx], 1u);
         };
-        for (int p = 1; p <= ((prm.debug_skip & 8u) ? 0 : max_p); ++p) {
-            if (pnarrow) {
-                partition_pass<G, true>(th, sh, p, flush);
-            } else {
-                partition_pass<G, false>(th, sh, p, flush);
+        if (prm.debug_skip & 8u) {
+            // (timing ablation only)
+        } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
+            partition_fused<G>(th, sh, max_p, flush);  // all orders in one walk (every full block, every probe)
+        } else {
+            for (int p = 1; p <= max_p; ++p) {
+                if (pnarrow) {
+                    partition_pass<G, true>(th, sh, p, flush);
+                } else {
+                    partition_pass<G, false>(th, sh, p, flush);
+                }
             }
         }
+        STAMP(19);
         __syncthreads();
+        STAMP(20);
         for (int idx = tid; idx < nseg; idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             const unsigned long long bits = seg_choose(sh, (uint32_t)idx, prm.zero_run);
@@ -579,6 +639,14 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         __syncthreads();
     }
     if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &plans[sidx]);
+    STAMP(21);
+#ifdef LACX_STAMPS
+    if ((tid & 63) == 0 && G::T == 1024) {
+        stamp_acc[22] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+        for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
+        atomicAdd(&g_stamp_acc[24], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -620,6 +688,18 @@ using GFull = Geo<16, 1024>;
 using GProbe = Geo<4, 64>;
 
 size_t analyze_smem_bytes_full() { return sizeof(Smem<GFull>); }
+
+int debug_read_stamps(unsigned long long* out32) {
+#ifdef LACX_STAMPS
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * 32) != hipSuccess) return 0;
+    unsigned long long zero[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof(zero));
+    return 1;
+#else
+    (void)out32;
+    return 0;
+#endif
+}
 size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
 
 static hipError_t set_smem_attr() {
@@ -653,13 +733,21 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     if (autost) {
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
-                           d_right, prm, 1, ws.lpcs, ws.need_probe, ws.plans);
+                           d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans);
         hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * (prm.channels == 2 ? 4u : 1u)), dim3(GFull::T),
-                       sizeof(Smem<GFull>), stream, d_left, d_right, prm, 0, ws.lpcs, ws.need_full, ws.plans);
+    const uint32_t per = prm.channels == 2 ? 2u : 1u;
+    hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * per), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left,
+                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans);
+    // Only a final block of <= 4096 frames can need all four channels (full LR-vs-MS comparison,
+    // ref lac/encoder.cpp:336-340): its 3rd and 4th slots go in a two-workgroup launch.
+    const uint64_t last_frames = prm.frames - (uint64_t)(nb - 1) * kMaxBlock;
+    if (autost && last_frames <= (uint64_t)kFullCompareLimit) {
+        hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left, d_right,
+                           prm, 0, nb - 1, 2, ws.lpcs, ws.need_full, ws.plans);
+    }
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (autost) {
         hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,

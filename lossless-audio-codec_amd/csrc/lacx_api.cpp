@@ -574,6 +574,8 @@ int lacx_block_encode(lacx_encoder* e, const int32_t* pcm, uint32_t n, uint8_t**
     return LACX_OK;
 }
 
+int lacx_debug_stamps(unsigned long long* out32) { return debug_read_stamps(out32); }
+
 int lacx_debug_lpc(lacx_encoder* e, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
                    uint8_t* used) {
     if (!e || !pcm || n == 0) return LACX_E_INVALID;

@@ -81,7 +81,7 @@ EXPORTS = (
     "lacx_encoder_create", "lacx_encoder_destroy", "lacx_last_error", "lacx_free", "lacx_get_timing",
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_assemble", "lacx_block_encode",
-    "lacx_block_plan_only", "lacx_debug_lpc", "lacx_device_count",
+    "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count",
 )
 
 

@@ -78,7 +78,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         scans_after_r(sh);
         plane_totals(sh, th);
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
-        const bool narrow = !force_wide && sh.tabP[G::T] < (1ull << 31);
+        const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
         for (int t = 0; t < G::T; ++t) {
             if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
         }
@@ -107,7 +107,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
     const int best = sh.best_cand;
     for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, best);
     scans_after_r(sh);
-    const bool pnarrow = !force_wide && sh.tabP[G::T] < (1ull << 31);
+    const bool pnarrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
     PartMem<G>& pm = sh.xp.part;
     int max_p = 0;
     if (partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
@@ -133,15 +133,20 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
             pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
             pm.segrun[i] = 0;
         }
+        auto flush = [&](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
+                         uint32_t hr) {
+            pm.segacc[idx][0] += rc;
+            pm.segacc[idx][1] += bn;
+            pm.segacc[idx][2] += zr;
+            pm.segrun[idx] |= hr;
+        };
+        const bool fused = pnarrow && !(force_wide & 2) && partitions_chunk_aligned<G>(n, max_p);
         for (int t = 0; t < G::T; ++t) {
+            if (fused) {
+                partition_fused<G>(th[t], sh, max_p, flush);
+                continue;
+            }
             for (int p = 1; p <= max_p; ++p) {
-                auto flush = [&](uint32_t idx, unsigned long long rc, unsigned long long bn,
-                                 unsigned long long zr, uint32_t hr) {
-                    pm.segacc[idx][0] += rc;
-                    pm.segacc[idx][1] += bn;
-                    pm.segacc[idx][2] += zr;
-                    pm.segrun[idx] |= hr;
-                };
                 if (pnarrow) partition_pass<G, true>(th[t], sh, p, flush); else partition_pass<G, false>(th[t], sh, p, flush);
             }
         }
@@ -162,7 +167,8 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
 extern "C" {
 
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
-// force_wide: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken
+// force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;
+// bit 1: use the per-order partition passes even where the fused pass applies
 int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
                    ChannelPlan* out) {
     if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);
