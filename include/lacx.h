@@ -78,12 +78,14 @@ typedef struct lacx_timing {
     double analysis_ms;     /* all kernels, device timeline (hipEvent) */
     double ingest_ms;       /* k_ingest + k_levinson */
     double probe_ms;        /* k_analyze<4,64> + k_decide */
-    double full_ms;         /* k_analyze<16,1024> (the dominant kernel) */
+    double full_ms;         /* k_analyze<16,1024> (the dominant kernel), summed over its launches */
     double d2h_ms;          /* plan records device -> host, incl. stream sync */
     double emit_ms;         /* host bit emit + container */
     double total_ms;        /* wall time of the call */
     uint64_t full_slots;    /* workgroups of the dominant kernel that did work */
     uint64_t probe_slots;
+    uint32_t full_launches; /* launches of the dominant kernel in the call (one per pipeline chunk) */
+    uint32_t reserved;
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);

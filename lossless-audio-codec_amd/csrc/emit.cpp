@@ -9,7 +9,9 @@
 #include "emit.h"
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "analyze_core.h"  // kmean(), zigzag32(), slot_fetch()
@@ -283,73 +285,181 @@ uint32_t block_payload_bytes(const StreamParams& sp, const BlockPlan& bp, const 
     return pair + (sp.stereo_mode == 2 ? 1u : 0u);
 }
 
+bool emit_one_block(const StreamParams& sp, const int32_t* left, const int32_t* right, uint64_t frames,
+                    const BlockPlan& bp, const ChannelPlan* slots, uint32_t b, uint8_t* out, size_t cap,
+                    int32_t* scratch) {
+    const uint64_t start = (uint64_t)b * kMaxBlock;
+    const uint64_t rem = frames - start;
+    const uint32_t n = rem < (uint64_t)kMaxBlock ? (uint32_t)rem : (uint32_t)kMaxBlock;
+    int kinds[2];
+    int nch = 1;
+    if (sp.channels == 1) {
+        kinds[0] = CH_L;
+    } else {
+        nch = 2;
+        const bool ms = bp.choose_ms != 0;
+        kinds[0] = ms ? CH_M : CH_L;
+        kinds[1] = ms ? CH_S : CH_R;
+        if (sp.stereo_mode == 2) {  // per-block flag byte (ref lac/encoder.cpp:363)
+            if (cap == 0) return false;
+            *out++ = ms ? 1 : 0;
+            --cap;
+        }
+    }
+    for (int c = 0; c < nch; ++c) {
+        const ChannelPlan& pl = slots[kinds[c]];
+        if (!pl.valid) return false;
+        const int32_t* a = (kinds[c] == CH_R) ? right + start : left + start;
+        const int32_t* bb = (kinds[c] >= CH_M) ? right + start : nullptr;
+        const size_t wrote = emit_channel(pl, a, bb, kinds[c], n, out, cap, scratch);
+        if (wrote == (size_t)-1 || wrote != pl.payload_bytes) return false;
+        out += wrote;
+        cap -= wrote;
+    }
+    return cap == 0;
+}
+
+struct EmitPool::Impl {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    bool stop = false;
+    uint64_t generation = 0;
+    // current job
+    StreamParams sp{};
+    const int32_t* left = nullptr;
+    const int32_t* right = nullptr;
+    uint64_t frames = 0;
+    const BlockPlan* bplans = nullptr;
+    const ChannelPlan* plans = nullptr;
+    const uint64_t* offsets = nullptr;
+    uint8_t* payload = nullptr;
+    uint32_t nblocks = 0;
+    std::atomic<uint32_t> next{0}, ready{0}, done{0};
+    std::atomic<int> failed{0};
+    unsigned active = 0;  // workers inside the current job
+
+    void run_job(std::vector<int32_t>& scratch) {
+        for (;;) {
+            const uint32_t b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks) return;
+            // wait until the block is published (or the job is aborted)
+            if (ready.load(std::memory_order_acquire) <= b) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return ready.load(std::memory_order_acquire) > b || failed.load() != 0; });
+            }
+            if (failed.load() == 0) {
+                const size_t cap = (size_t)(offsets[b + 1] - offsets[b]);
+                if (!emit_one_block(sp, left, right, frames, bplans[b], plans + (size_t)b * kSlotsPerBlock, b,
+                                    payload + offsets[b], cap, scratch.data()))
+                    failed.store(1);
+            }
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+
+    void worker_main() {
+        std::vector<int32_t> scratch(kMaxBlock);
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                ++active;
+            }
+            run_job(scratch);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                --active;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+EmitPool::EmitPool(unsigned threads) : impl_(new Impl) {
+    unsigned nt = threads ? threads : std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    impl_->workers.reserve(nt);
+    for (unsigned t = 0; t < nt; ++t) impl_->workers.emplace_back([this] { impl_->worker_main(); });
+}
+
+EmitPool::~EmitPool() {
+    {
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->stop = true;
+    }
+    impl_->cv_work.notify_all();
+    for (auto& t : impl_->workers) t.join();
+    delete impl_;
+}
+
+unsigned EmitPool::threads() const { return (unsigned)impl_->workers.size(); }
+
+void EmitPool::begin(const StreamParams& sp, const int32_t* left, const int32_t* right, uint64_t frames,
+                     const BlockPlan* bplans, const ChannelPlan* plans, uint32_t nblocks, const uint64_t* offsets,
+                     uint8_t* payload) {
+    {
+        std::unique_lock<std::mutex> lk(impl_->mu);
+        impl_->cv_done.wait(lk, [&] { return impl_->active == 0; });  // no straggler of the previous job
+        impl_->sp = sp;
+        impl_->left = left;
+        impl_->right = right;
+        impl_->frames = frames;
+        impl_->bplans = bplans;
+        impl_->plans = plans;
+        impl_->offsets = offsets;
+        impl_->payload = payload;
+        impl_->nblocks = nblocks;
+        impl_->next.store(0);
+        impl_->ready.store(0);
+        impl_->done.store(0);
+        impl_->failed.store(0);
+        ++impl_->generation;
+    }
+    impl_->cv_work.notify_all();
+}
+
+void EmitPool::publish(uint32_t ready_upto) {
+    {
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->ready.store(ready_upto, std::memory_order_release);
+    }
+    impl_->cv_work.notify_all();
+}
+
+void EmitPool::abort() {
+    {
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->failed.store(1);
+    }
+    impl_->cv_work.notify_all();
+}
+
+bool EmitPool::finish() {
+    {
+        // the calling thread helps; it also guarantees progress with a pool of size zero
+        std::vector<int32_t> scratch(kMaxBlock);
+        impl_->run_job(scratch);
+    }
+    std::unique_lock<std::mutex> lk(impl_->mu);
+    impl_->cv_done.wait(lk, [&] { return impl_->done.load(std::memory_order_acquire) >= impl_->nblocks && impl_->active == 0; });
+    return impl_->failed.load() == 0;
+}
+
 std::string emit_blocks(const StreamParams& sp, const int32_t* left, const int32_t* right, uint64_t frames,
                         const BlockPlan* bplans, const ChannelPlan* plans, uint32_t nblocks,
                         const uint64_t* offsets, uint8_t* payload, uint64_t payload_size, unsigned threads) {
-    std::atomic<uint32_t> next{0};
-    std::atomic<int> failed{0};
-    std::string err;
-    auto worker = [&]() {
-        std::vector<int32_t> scratch(kMaxBlock);
-        for (;;) {
-            const uint32_t b = next.fetch_add(1);
-            if (b >= nblocks || failed.load()) return;
-            const uint64_t start = (uint64_t)b * kMaxBlock;
-            const uint64_t rem = frames - start;
-            const uint32_t n = rem < (uint64_t)kMaxBlock ? (uint32_t)rem : (uint32_t)kMaxBlock;
-            const ChannelPlan* slots = plans + (size_t)b * kSlotsPerBlock;
-            uint8_t* out = payload + offsets[b];
-            const uint64_t end = (b + 1 < nblocks) ? offsets[b + 1] : payload_size;
-            size_t cap = (size_t)(end - offsets[b]);
-            int kinds[2];
-            int nch = 1;
-            if (sp.channels == 1) {
-                kinds[0] = CH_L;
-            } else {
-                nch = 2;
-                const bool ms = bplans[b].choose_ms != 0;
-                kinds[0] = ms ? CH_M : CH_L;
-                kinds[1] = ms ? CH_S : CH_R;
-                if (sp.stereo_mode == 2) {  // per-block flag byte (ref lac/encoder.cpp:363)
-                    if (cap == 0) {
-                        failed = 1;
-                        return;
-                    }
-                    *out++ = ms ? 1 : 0;
-                    --cap;
-                }
-            }
-            for (int c = 0; c < nch; ++c) {
-                const ChannelPlan& pl = slots[kinds[c]];
-                const int32_t* a = (kinds[c] == CH_R) ? right + start : left + start;
-                const int32_t* bb = (kinds[c] >= CH_M) ? right + start : nullptr;
-                const size_t wrote = pl.valid ? emit_channel(pl, a, bb, kinds[c], n, out, cap, scratch.data())
-                                              : (size_t)-1;
-                if (wrote == (size_t)-1 || wrote != pl.payload_bytes) {
-                    failed = 1;
-                    return;
-                }
-                out += wrote;
-                cap -= wrote;
-            }
-            if (cap != 0) {
-                failed = 1;
-                return;
-            }
-        }
-    };
+    std::vector<uint64_t> offs(offsets, offsets + nblocks);
+    offs.push_back(payload_size);
     unsigned nt = threads ? threads : std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
     if (nt > nblocks) nt = nblocks;
-    if (nt <= 1) {
-        worker();
-    } else {
-        std::vector<std::thread> pool;
-        pool.reserve(nt);
-        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
-        for (auto& t : pool) t.join();
-    }
-    if (failed.load()) return "emitted size disagrees with the device plan (internal error)";
+    EmitPool pool(nt > 1 ? nt - 1 : 0);
+    pool.begin(sp, left, right, frames, bplans, plans, nblocks, offs.data(), payload);
+    pool.publish(nblocks);
+    if (!pool.finish()) return "emitted size disagrees with the device plan (internal error)";
     return std::string();
 }
 

@@ -35,6 +35,36 @@ std::string emit_blocks(const StreamParams& sp, const int32_t* left, const int32
                         const BlockPlan* bplans, const ChannelPlan* plans, uint32_t nblocks,
                         const uint64_t* offsets, uint8_t* payload, uint64_t payload_size, unsigned threads);
 
+// Emits block `b` ([flag] + channel payloads) into out[0..cap); cap must equal block_payload_bytes.
+// Returns false when the emitted size disagrees with the plan.
+bool emit_one_block(const StreamParams& sp, const int32_t* left, const int32_t* right, uint64_t frames,
+                    const BlockPlan& bp, const ChannelPlan* slots, uint32_t b, uint8_t* out, size_t cap,
+                    int32_t* scratch /* kMaxBlock int32 */);
+
+// Persistent emit workers.  A job covers blocks [0, nblocks); a block becomes eligible once
+// publish(upto) has been called with upto > block (its plan records and byte offset are then final),
+// which lets the emit of early blocks overlap the device analysis of later ones.
+class EmitPool {
+public:
+    explicit EmitPool(unsigned threads);
+    ~EmitPool();
+    EmitPool(const EmitPool&) = delete;
+    EmitPool& operator=(const EmitPool&) = delete;
+
+    unsigned threads() const;
+    // offsets has nblocks + 1 entries, filled in by the caller before the matching publish().
+    void begin(const StreamParams& sp, const int32_t* left, const int32_t* right, uint64_t frames,
+               const BlockPlan* bplans, const ChannelPlan* plans, uint32_t nblocks, const uint64_t* offsets,
+               uint8_t* payload);
+    void publish(uint32_t ready_upto);
+    void abort();
+    bool finish();  // waits for every block; false if any block failed or the job was aborted
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
 // 10-byte frame header (ref src/codec/frame/frame_header.hpp:25-36).
 void write_frame_header(const StreamParams& sp, uint8_t* out10);
 

@@ -1,14 +1,20 @@
 // lacx_api.cpp -- implementation of the C ABI declared in include/lacx.h.
 //
-// Thin host layer: owns the HIP stream, the device workspace and pinned plan buffers, enqueues the
+// Thin host layer: owns the HIP streams, the device workspace and pinned plan buffers, enqueues the
 // kernels (kernels.hip), and runs the host emit (emit.cpp) from the returned plan records.
+// Encode calls are pipelined: the stream is cut into chunks of blocks whose kernels alternate between
+// two HIP streams; as soon as a chunk's plan records have landed in pinned host memory the emit
+// workers start on its blocks while the GPU analyses the next chunk.
 // There is no CPU analysis path here: without a usable HIP device every analysing call fails.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "emit.h"
@@ -21,12 +27,19 @@ static_assert(sizeof(lacx_channel_plan) == sizeof(ChannelPlan), "ABI plan layout
 static_assert(sizeof(lacx_block_plan) == sizeof(BlockPlan), "ABI block plan layout");
 static_assert(sizeof(ChannelPlan) == 296, "ChannelPlan layout");
 
+namespace {
+constexpr int kStreams = 2;
+constexpr int kMaxChunks = 16;
+constexpr uint32_t kMinChunkBlocks = 192;  // >= 1.5 rounds of 1024-thread workgroups over 256 CUs
+}  // namespace
+
 struct lacx_encoder {
     lacx_config cfg{};
     bool device_ready = false;
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {};
+    hipStream_t stream[kStreams] = {};
+    hipEvent_t ev[kMaxChunks][5] = {};
+    hipEvent_t done[kMaxChunks] = {};
     DeviceWorkspace ws{};
     uint32_t ws_blocks = 0;
     int32_t* d_left = nullptr;
@@ -35,6 +48,7 @@ struct lacx_encoder {
     ChannelPlan* h_plans = nullptr;  // pinned
     BlockPlan* h_bplans = nullptr;   // pinned
     uint32_t h_blocks = 0;
+    std::unique_ptr<EmitPool> pool;
     std::string err;
     lacx_timing timing{};
 };
@@ -53,9 +67,9 @@ int hip_fail(lacx_encoder* e, hipError_t err, const char* what) {
     return fail(e, LACX_E_DEVICE, std::string(what) + ": " + hipGetErrorString(err));
 }
 
-#define HIP_TRY(e, call, what)                          \
-    do {                                                \
-        const hipError_t _err = (call);                 \
+#define HIP_TRY(e, call, what)                                  \
+    do {                                                        \
+        const hipError_t _err = (call);                         \
         if (_err != hipSuccess) return hip_fail(e, _err, what); \
     } while (0)
 
@@ -70,10 +84,21 @@ int ensure_device(lacx_encoder* e) {
     if (dev >= count) return fail(e, LACX_E_DEVICE, "HIP device ordinal out of range");
     HIP_TRY(e, hipSetDevice(dev), "hipSetDevice");
     e->device = dev;
-    HIP_TRY(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate");
-    for (auto& ev : e->ev) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
+    for (auto& s : e->stream) HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto& row : e->ev)
+        for (auto& ev : row) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
+    for (auto& ev : e->done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     e->device_ready = true;
     return LACX_OK;
+}
+
+EmitPool& pool_of(lacx_encoder* e) {
+    if (!e->pool) {
+        unsigned nt = e->cfg.emit_threads ? e->cfg.emit_threads : std::thread::hardware_concurrency();
+        if (nt == 0) nt = 1;
+        e->pool.reset(new EmitPool(nt > 1 ? nt - 1 : 0));  // the calling thread is the last worker
+    }
+    return *e->pool;
 }
 
 void free_workspace(lacx_encoder* e) {
@@ -143,52 +168,80 @@ int validate_stream_args(lacx_encoder* e, const void* left, uint64_t frames) {
 
 uint32_t blocks_for(uint64_t frames) { return (uint32_t)((frames + kMaxBlock - 1) / kMaxBlock); }
 
-// Runs the kernels on device-resident PCM; leaves plans in the pinned host buffers.
-int analyze_on_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
-                      int channels, int stereo_mode, int bit_depth, hipStream_t stream) {
-    const uint32_t nb = blocks_for(frames);
-    int rc = ensure_workspace(e, nb);
-    if (rc) return rc;
+AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, int stereo_mode, int bit_depth) {
     AnalyzeParams prm{};
     prm.frames = frames;
-    prm.num_blocks = nb;
+    prm.num_blocks = blocks_for(frames);
     prm.first_block = 0;
     prm.channels = channels;
     prm.stereo_mode = channels == 2 ? stereo_mode : 0;
     prm.bit_depth = bit_depth;
     prm.zero_run = e->cfg.zero_run_enabled ? 1 : 0;
     prm.partitioning = e->cfg.partitioning_enabled ? 1 : 0;
-    {
-        const char* dbg = std::getenv("LACX_DEBUG_SKIP");  // timing ablations only
-        prm.debug_skip = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
-    }
-    HIP_TRY(e, launch_analysis(d_left, d_right, prm, e->ws, stream, e->ev), "kernel launch");
-    const auto t0 = clk::now();
-    HIP_TRY(e, hipMemcpyAsync(e->h_plans, e->ws.plans, (size_t)nb * kSlotsPerBlock * sizeof(ChannelPlan),
-                              hipMemcpyDeviceToHost, stream),
-            "D2H plans");
-    HIP_TRY(e, hipMemcpyAsync(e->h_bplans, e->ws.bplans, (size_t)nb * sizeof(BlockPlan), hipMemcpyDeviceToHost,
-                              stream),
-            "D2H block plans");
-    HIP_TRY(e, hipStreamSynchronize(stream), "stream synchronize");
-    e->timing.d2h_ms = ms_since(t0);  // includes waiting for the kernels when called back to back
+    const char* dbg = std::getenv("LACX_DEBUG_SKIP");  // timing ablations only
+    prm.debug_skip = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
+    return prm;
+}
+
+DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
+    DeviceWorkspace w = ws;
+    const size_t s = (size_t)first_block * kSlotsPerBlock;
+    w.plans += s;
+    w.bplans += first_block;
+    w.need_probe += first_block;
+    w.need_full += first_block;
+    w.acorr += s * 13;
+    w.lpcs += s;
+    return w;
+}
+
+struct Chunk {
+    uint32_t first, count;
+};
+
+std::vector<Chunk> plan_chunks(uint32_t nb) {
+    uint32_t nchunks = nb / kMinChunkBlocks;
+    nchunks = std::max(1u, std::min(nchunks, 8u));
+    const uint32_t per = (nb + nchunks - 1) / nchunks;
+    std::vector<Chunk> out;
+    for (uint32_t f = 0; f < nb; f += per) out.push_back({f, std::min(per, nb - f)});
+    return out;
+}
+
+void add_chunk_timing(lacx_encoder* e, int c) {
     float f = 0;
-    (void)hipEventElapsedTime(&f, e->ev[0], e->ev[4]);
-    e->timing.analysis_ms = f;
-    (void)hipEventElapsedTime(&f, e->ev[0], e->ev[1]);
-    e->timing.ingest_ms = f;
-    (void)hipEventElapsedTime(&f, e->ev[1], e->ev[2]);
-    e->timing.probe_ms = f;
-    (void)hipEventElapsedTime(&f, e->ev[2], e->ev[3]);
-    e->timing.full_ms = f;
+    if (hipEventElapsedTime(&f, e->ev[c][0], e->ev[c][4]) == hipSuccess) e->timing.analysis_ms += f;
+    if (hipEventElapsedTime(&f, e->ev[c][0], e->ev[c][1]) == hipSuccess) e->timing.ingest_ms += f;
+    if (hipEventElapsedTime(&f, e->ev[c][1], e->ev[c][2]) == hipSuccess) e->timing.probe_ms += f;
+    if (hipEventElapsedTime(&f, e->ev[c][2], e->ev[c][3]) == hipSuccess) e->timing.full_ms += f;
+}
+
+void count_slots(lacx_encoder* e, uint32_t first, uint32_t count) {
     uint64_t fs = 0, ps = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
+    for (uint32_t b = first; b < first + count; ++b) {
         const ChannelPlan* s = e->h_plans + (size_t)b * kSlotsPerBlock;
         for (int i = 0; i < 4; ++i) fs += s[i].valid;
         for (int i = 4; i < kSlotsPerBlock; ++i) ps += s[i].valid;
     }
-    e->timing.full_slots = fs;
-    e->timing.probe_slots = ps;
+    e->timing.full_slots += fs;
+    e->timing.probe_slots += ps;
+}
+
+// Enqueues the kernels + plan D2H of one chunk on stream `st`, then records done[c].
+int enqueue_chunk(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, int channels,
+                  int stereo_mode, int bit_depth, const Chunk& ck, int c, hipStream_t st) {
+    const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
+    const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
+    const AnalyzeParams prm = make_params(e, f1 - f0, channels, stereo_mode, bit_depth);
+    const DeviceWorkspace w = ws_at(e->ws, ck.first);
+    HIP_TRY(e, launch_analysis(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, st, e->ev[c]), "kernel launch");
+    HIP_TRY(e, hipMemcpyAsync(e->h_plans + (size_t)ck.first * kSlotsPerBlock, w.plans,
+                              (size_t)ck.count * kSlotsPerBlock * sizeof(ChannelPlan), hipMemcpyDeviceToHost, st),
+            "D2H plans");
+    HIP_TRY(e, hipMemcpyAsync(e->h_bplans + ck.first, w.bplans, (size_t)ck.count * sizeof(BlockPlan),
+                              hipMemcpyDeviceToHost, st),
+            "D2H block plans");
+    HIP_TRY(e, hipEventRecord(e->done[c], st), "event record");
     return LACX_OK;
 }
 
@@ -199,11 +252,8 @@ int check_sample_range(lacx_encoder* e, uint32_t nb) {
             const BlockPlan& bp = e->h_bplans[b];
             if (!bp.invalid) continue;
             const bool is_right = (bp.first_bad >> 31) != 0;
-            if ((pass == 0) != !is_right) {
-                // a block whose first bad sample is on the right may still hide a left one only if the
-                // left channel of that block is clean (left wins the per-block minimum), so this is exact
-                continue;
-            }
+            // per block the left channel wins the minimum, so a "right" entry means a clean left channel
+            if ((pass == 0) == is_right) continue;
             const uint64_t idx = (uint64_t)b * kMaxBlock + (bp.first_bad & 0x7FFFFFFFu);
             return fail(e, LACX_E_INVALID,
                         std::string(is_right ? "right" : "left") + " sample at index " + std::to_string(idx) +
@@ -213,20 +263,29 @@ int check_sample_range(lacx_encoder* e, uint32_t nb) {
     return LACX_OK;
 }
 
-struct ShardOut {
-    std::vector<uint64_t> offsets;
-    uint64_t payload_size = 0;
-};
+void reset_device_timing(lacx_encoder* e) {
+    e->timing.analysis_ms = e->timing.ingest_ms = e->timing.probe_ms = e->timing.full_ms = 0;
+    e->timing.full_slots = e->timing.probe_slots = 0;
+    e->timing.full_launches = 0;
+}
 
-void layout_payload(const StreamParams& sp, const BlockPlan* bp, const ChannelPlan* plans, uint32_t nb,
-                    ShardOut& so) {
-    so.offsets.resize(nb);
-    uint64_t off = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
-        so.offsets[b] = off;
-        off += block_payload_bytes(sp, bp[b], plans + (size_t)b * kSlotsPerBlock);
-    }
-    so.payload_size = off;
+// Runs the kernels on device-resident PCM in one launch set on `st`; leaves plans in the pinned buffers.
+int analyze_on_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                      int channels, int stereo_mode, int bit_depth, hipStream_t st) {
+    const uint32_t nb = blocks_for(frames);
+    int rc = ensure_workspace(e, nb);
+    if (rc) return rc;
+    const auto t0 = clk::now();
+    const Chunk all{0, nb};
+    rc = enqueue_chunk(e, d_left, d_right, frames, channels, stereo_mode, bit_depth, all, 0, st);
+    if (rc) return rc;
+    HIP_TRY(e, hipEventSynchronize(e->done[0]), "event synchronize");
+    e->timing.d2h_ms = ms_since(t0);
+    reset_device_timing(e);
+    add_chunk_timing(e, 0);
+    e->timing.full_launches = 1;
+    count_slots(e, 0, nb);
+    return LACX_OK;
 }
 
 StreamParams stream_params(const lacx_config& c, int channels) {
@@ -245,74 +304,108 @@ void put32(uint8_t* p, uint32_t v) {
     p[3] = (uint8_t)v;
 }
 
-// header + block table + payloads from host plans (ref lac/encoder.cpp:243-250, 445-465)
-int emit_stream(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
-                const BlockPlan* bplans, const ChannelPlan* plans, uint8_t** out, uint64_t* out_size) {
-    const auto t0 = clk::now();
-    const int channels = right ? 2 : 1;
+// Bytes reserved for the payload of a shard.  The buffer is virtual memory until touched, so the bound
+// is generous: 12 bytes per sample (the costliest realistic material, full-scale 24-bit noise, needs
+// about 3.3).  The real size is known from the plans before any block is published; a stream that
+// exceeded the reservation (only constructible with adversarial data) is reported as a runtime error
+// instead of overrunning the buffer.
+uint64_t payload_upper_bound(uint64_t frames, int channels, uint32_t nb) {
+    return frames * (uint64_t)channels * 12u + (uint64_t)nb * 1024u + 64u;
+}
+
+// Pipelined analysis + emit.  `head` bytes are reserved in front of the payload (container header +
+// table for whole-stream calls, 0 for shards).  On success *buf_out holds head + payload (malloc'd).
+int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, const int32_t* h_left,
+                     const int32_t* h_right, uint64_t frames, hipStream_t user_stream, uint64_t head,
+                     uint8_t** buf_out, uint64_t* payload_size, std::vector<uint64_t>& offsets) {
+    const int channels = d_right ? 2 : 1;
     const uint32_t nb = blocks_for(frames);
+    int rc = ensure_workspace(e, nb);
+    if (rc) return rc;
     const StreamParams sp = stream_params(e->cfg, channels);
-    ShardOut so;
-    layout_payload(sp, bplans, plans, nb, so);
-    const uint64_t head = 10 + 4 + 8ull * nb;
-    uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + so.payload_size));
+    const std::vector<Chunk> chunks = plan_chunks(nb);
+    const uint64_t cap = payload_upper_bound(frames, channels, nb);
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + cap));
     if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
-    write_frame_header(sp, buf);
-    put32(buf + 10, nb);
-    for (uint32_t b = 0; b < nb; ++b) {
-        const uint64_t size = ((b + 1 < nb) ? so.offsets[b + 1] : so.payload_size) - so.offsets[b];
-        if (size == 0 || size > 0xFFFFFFFFull) {
+    offsets.assign((size_t)nb + 1, 0);
+
+    reset_device_timing(e);
+    const auto t0 = clk::now();
+    // the caller's stream (if any) carries chunks 0, 2, ...; the encoder's second stream the others
+    hipStream_t st[kStreams] = {user_stream ? user_stream : e->stream[0], e->stream[1]};
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        rc = enqueue_chunk(e, d_left, d_right, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, chunks[c],
+                           (int)c, st[c % kStreams]);
+        if (rc) {
+            (void)hipDeviceSynchronize();
             std::free(buf);
-            return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+            return rc;
         }
-        put32(buf + 14 + 8ull * b, bplans[b].frames);
-        put32(buf + 18 + 8ull * b, (uint32_t)size);
     }
-    const std::string err = emit_blocks(sp, left, right, frames, bplans, plans, nb, so.offsets.data(), buf + head,
-                                        so.payload_size, e->cfg.emit_threads);
-    if (!err.empty()) {
+    EmitPool& pool = pool_of(e);
+    pool.begin(sp, h_left, h_right, frames, e->h_bplans, e->h_plans, nb, offsets.data(), buf + head);
+    uint64_t off = 0;
+    int status = LACX_OK;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const hipError_t he = hipEventSynchronize(e->done[c]);
+        if (he != hipSuccess) {
+            status = hip_fail(e, he, "event synchronize");
+            break;
+        }
+        const Chunk& ck = chunks[c];
+        bool bad = false;
+        for (uint32_t b = ck.first; b < ck.first + ck.count; ++b) {
+            if (e->h_bplans[b].invalid) bad = true;
+            offsets[b] = off;
+            off += block_payload_bytes(sp, e->h_bplans[b], e->h_plans + (size_t)b * kSlotsPerBlock);
+        }
+        offsets[ck.first + ck.count] = off;
+        if (bad || off > cap) {
+            status = bad ? LACX_E_INVALID : fail(e, LACX_E_RUNTIME, "payload exceeds the reserved bound");
+            break;
+        }
+        pool.publish(ck.first + ck.count);
+    }
+    e->timing.d2h_ms = ms_since(t0);
+    if (status != LACX_OK) {
+        pool.abort();
+        (void)pool.finish();
+        (void)hipDeviceSynchronize();
         std::free(buf);
-        return fail(e, LACX_E_RUNTIME, err);
+        if (status == LACX_E_INVALID) {
+            const int rr = check_sample_range(e, nb);  // formats the reference's message
+            return rr ? rr : fail(e, LACX_E_INVALID, "sample outside the configured PCM bit depth");
+        }
+        return status;
     }
-    *out = buf;
-    *out_size = head + so.payload_size;
-    e->timing.emit_ms = ms_since(t0);
+    const bool ok = pool.finish();
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        add_chunk_timing(e, (int)c);
+        count_slots(e, chunks[c].first, chunks[c].count);
+    }
+    e->timing.full_launches = (uint32_t)chunks.size();
+    if (!ok) {
+        std::free(buf);
+        return fail(e, LACX_E_RUNTIME, "emitted size disagrees with the device plan (internal error)");
+    }
+    uint8_t* shrunk = static_cast<uint8_t*>(std::realloc(buf, (head + off) ? (head + off) : 1));
+    *buf_out = shrunk ? shrunk : buf;
+    *payload_size = off;
     return LACX_OK;
 }
 
-int emit_shard(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
-               const BlockPlan* bplans, const ChannelPlan* plans, uint8_t** payload, uint64_t* payload_size,
-               uint32_t** table, uint32_t* nblocks) {
-    const auto t0 = clk::now();
-    const int channels = right ? 2 : 1;
-    const uint32_t nb = blocks_for(frames);
-    const StreamParams sp = stream_params(e->cfg, channels);
-    ShardOut so;
-    layout_payload(sp, bplans, plans, nb, so);
-    uint8_t* buf = static_cast<uint8_t*>(std::malloc(so.payload_size ? so.payload_size : 1));
-    uint32_t* tab = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * 2 * (nb ? nb : 1)));
-    if (!buf || !tab) {
-        std::free(buf);
-        std::free(tab);
-        return fail(e, LACX_E_RUNTIME, "out of memory");
+int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                        const int32_t*& h_left, const int32_t*& h_right, std::vector<int32_t>& tl,
+                        std::vector<int32_t>& tr) {
+    if (h_left) return LACX_OK;
+    tl.resize(frames);
+    HIP_TRY(e, hipMemcpy(tl.data(), d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
+    h_left = tl.data();
+    if (d_right) {
+        tr.resize(frames);
+        HIP_TRY(e, hipMemcpy(tr.data(), d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
+        h_right = tr.data();
     }
-    for (uint32_t b = 0; b < nb; ++b) {
-        const uint64_t size = ((b + 1 < nb) ? so.offsets[b + 1] : so.payload_size) - so.offsets[b];
-        tab[2 * b] = bplans[b].frames;
-        tab[2 * b + 1] = (uint32_t)size;
-    }
-    const std::string err = emit_blocks(sp, left, right, frames, bplans, plans, nb, so.offsets.data(), buf,
-                                        so.payload_size, e->cfg.emit_threads);
-    if (!err.empty()) {
-        std::free(buf);
-        std::free(tab);
-        return fail(e, LACX_E_RUNTIME, err);
-    }
-    *payload = buf;
-    *payload_size = so.payload_size;
-    *table = tab;
-    *nblocks = nb;
-    e->timing.emit_ms = ms_since(t0);
     return LACX_OK;
 }
 
@@ -320,12 +413,34 @@ int upload(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t 
     const auto t0 = clk::now();
     int rc = ensure_pcm(e, frames, right != nullptr);
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->d_left, left, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream), "H2D left");
+    HIP_TRY(e, hipMemcpyAsync(e->d_left, left, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream[0]),
+            "H2D left");
     if (right)
-        HIP_TRY(e, hipMemcpyAsync(e->d_right, right, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream),
+        HIP_TRY(e, hipMemcpyAsync(e->d_right, right, frames * sizeof(int32_t), hipMemcpyHostToDevice, e->stream[0]),
                 "H2D right");
-    HIP_TRY(e, hipStreamSynchronize(e->stream), "H2D synchronize");
+    HIP_TRY(e, hipStreamSynchronize(e->stream[0]), "H2D synchronize");
     e->timing.h2d_ms = ms_since(t0);
+    return LACX_OK;
+}
+
+int prepare(lacx_encoder* e, const void* left, uint64_t frames) {
+    int rc = validate_stream_args(e, left, frames);
+    if (rc) return rc;
+    rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    return LACX_OK;
+}
+
+int fill_table(lacx_encoder* e, uint8_t* buf, uint32_t nb, const std::vector<uint64_t>& offsets) {
+    put32(buf + 10, nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t size = offsets[b + 1] - offsets[b];
+        if (size == 0 || size > 0xFFFFFFFFull)
+            return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+        put32(buf + 14 + 8ull * b, e->h_bplans[b].frames);
+        put32(buf + 18 + 8ull * b, (uint32_t)size);
+    }
     return LACX_OK;
 }
 
@@ -349,6 +464,7 @@ int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out) {
 
 void lacx_encoder_destroy(lacx_encoder* e) {
     if (!e) return;
+    e->pool.reset();
     if (e->device_ready) {
         (void)hipSetDevice(e->device);
         free_workspace(e);
@@ -356,9 +472,13 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->d_right) (void)hipFree(e->d_right);
         if (e->h_plans) (void)hipHostFree(e->h_plans);
         if (e->h_bplans) (void)hipHostFree(e->h_bplans);
-        for (auto& ev : e->ev)
+        for (auto& row : e->ev)
+            for (auto& ev : row)
+                if (ev) (void)hipEventDestroy(ev);
+        for (auto& ev : e->done)
             if (ev) (void)hipEventDestroy(ev);
-        if (e->stream) (void)hipStreamDestroy(e->stream);
+        for (auto& s : e->stream)
+            if (s) (void)hipStreamDestroy(s);
     }
     delete e;
 }
@@ -374,13 +494,10 @@ void lacx_get_timing(const lacx_encoder* e, lacx_timing* out) {
 int lacx_analyze_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                         void* stream, lacx_block_plan* bplans, lacx_channel_plan* plans) {
     if (!e) return LACX_E_INVALID;
-    int rc = validate_stream_args(e, d_left, frames);
+    int rc = prepare(e, d_left, frames);
     if (rc) return rc;
-    rc = ensure_device(e);
-    if (rc) return rc;
-    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     const int channels = d_right ? 2 : 1;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : e->stream[0];
     rc = analyze_on_device(e, d_left, d_right, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, st);
     if (rc) return rc;
     const uint32_t nb = blocks_for(frames);
@@ -392,24 +509,54 @@ int lacx_analyze_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d
 int lacx_analyze(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
                  lacx_block_plan* bplans, lacx_channel_plan* plans) {
     if (!e) return LACX_E_INVALID;
-    int rc = validate_stream_args(e, left, frames);
+    int rc = prepare(e, left, frames);
     if (rc) return rc;
-    rc = ensure_device(e);
-    if (rc) return rc;
-    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     rc = upload(e, left, right, frames);
     if (rc) return rc;
     return lacx_analyze_device(e, e->d_left, right ? e->d_right : nullptr, frames, nullptr, bplans, plans);
 }
 
 int lacx_emit_from_plans(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
-                         const lacx_block_plan* bplans, const lacx_channel_plan* plans, uint8_t** out,
+                         const lacx_block_plan* bplans_c, const lacx_channel_plan* plans_c, uint8_t** out,
                          uint64_t* out_size) {
-    if (!e || !out || !out_size || !bplans || !plans) return LACX_E_INVALID;
+    if (!e || !out || !out_size || !bplans_c || !plans_c) return LACX_E_INVALID;
     const int rc = validate_stream_args(e, left, frames);
     if (rc) return rc;
-    return emit_stream(e, left, right, frames, reinterpret_cast<const BlockPlan*>(bplans),
-                       reinterpret_cast<const ChannelPlan*>(plans), out, out_size);
+    const BlockPlan* bplans = reinterpret_cast<const BlockPlan*>(bplans_c);
+    const ChannelPlan* plans = reinterpret_cast<const ChannelPlan*>(plans_c);
+    const int channels = right ? 2 : 1;
+    const uint32_t nb = blocks_for(frames);
+    const StreamParams sp = stream_params(e->cfg, channels);
+    std::vector<uint64_t> offsets((size_t)nb + 1, 0);
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        offsets[b] = off;
+        off += block_payload_bytes(sp, bplans[b], plans + (size_t)b * kSlotsPerBlock);
+    }
+    offsets[nb] = off;
+    const uint64_t head = 10 + 4 + 8ull * nb;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + off));
+    if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
+    write_frame_header(sp, buf);
+    put32(buf + 10, nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t size = offsets[b + 1] - offsets[b];
+        if (size == 0 || size > 0xFFFFFFFFull) {
+            std::free(buf);
+            return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+        }
+        put32(buf + 14 + 8ull * b, bplans[b].frames);
+        put32(buf + 18 + 8ull * b, (uint32_t)size);
+    }
+    const std::string err = emit_blocks(sp, left, right, frames, bplans, plans, nb, offsets.data(), buf + head, off,
+                                        e->cfg.emit_threads);
+    if (!err.empty()) {
+        std::free(buf);
+        return fail(e, LACX_E_RUNTIME, err);
+    }
+    *out = buf;
+    *out_size = head + off;
+    return LACX_OK;
 }
 
 int lacx_encode_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, const int32_t* h_left,
@@ -417,23 +564,33 @@ int lacx_encode_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_
                        uint64_t* out_size) {
     if (!e || !out || !out_size) return LACX_E_INVALID;
     const auto t0 = clk::now();
+    const double h2d = e->timing.h2d_ms;
     e->timing = lacx_timing{};
-    int rc = lacx_analyze_device(e, d_left, d_right, frames, stream, nullptr, nullptr);
+    e->timing.h2d_ms = h2d;
+    int rc = prepare(e, d_left, frames);
     if (rc) return rc;
-    std::vector<int32_t> tmp_l, tmp_r;
-    if (!h_left) {  // no host copy supplied: fetch the PCM for the host emit
-        tmp_l.resize(frames);
-        HIP_TRY(e, hipMemcpy(tmp_l.data(), d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
-        h_left = tmp_l.data();
-        if (d_right) {
-            tmp_r.resize(frames);
-            HIP_TRY(e, hipMemcpy(tmp_r.data(), d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H pcm");
-            h_right = tmp_r.data();
-        }
+    std::vector<int32_t> tl, tr;
+    rc = fetch_pcm_if_needed(e, d_left, d_right, frames, h_left, h_right, tl, tr);
+    if (rc) return rc;
+    const uint32_t nb = blocks_for(frames);
+    const uint64_t head = 10 + 4 + 8ull * nb;
+    uint8_t* buf = nullptr;
+    uint64_t pay = 0;
+    std::vector<uint64_t> offsets;
+    rc = encode_pipelined(e, d_left, d_right, h_left, d_right ? h_right : nullptr, frames,
+                          static_cast<hipStream_t>(stream), head, &buf, &pay, offsets);
+    if (rc) return rc;
+    write_frame_header(stream_params(e->cfg, d_right ? 2 : 1), buf);
+    rc = fill_table(e, buf, nb, offsets);
+    if (rc) {
+        std::free(buf);
+        return rc;
     }
-    rc = emit_stream(e, h_left, d_right ? h_right : nullptr, frames, e->h_bplans, e->h_plans, out, out_size);
+    *out = buf;
+    *out_size = head + pay;
     e->timing.total_ms = ms_since(t0);
-    return rc;
+    e->timing.emit_ms = e->timing.total_ms - e->timing.d2h_ms;
+    return LACX_OK;
 }
 
 int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames, uint8_t** out,
@@ -441,18 +598,11 @@ int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint
     if (!e || !out || !out_size) return LACX_E_INVALID;
     const auto t0 = clk::now();
     e->timing = lacx_timing{};
-    int rc = validate_stream_args(e, left, frames);
+    int rc = prepare(e, left, frames);
     if (rc) return rc;
-    rc = ensure_device(e);
-    if (rc) return rc;
-    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     rc = upload(e, left, right, frames);
     if (rc) return rc;
-    const double h2d = e->timing.h2d_ms;
-    rc = lacx_analyze_device(e, e->d_left, right ? e->d_right : nullptr, frames, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    rc = emit_stream(e, left, right, frames, e->h_bplans, e->h_plans, out, out_size);
-    e->timing.h2d_ms = h2d;
+    rc = lacx_encode_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr, out, out_size);
     e->timing.total_ms = ms_since(t0);
     return rc;
 }
@@ -462,23 +612,42 @@ int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32
                              uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
     if (!e || !payload || !payload_size || !table || !nblocks || !h_left) return LACX_E_INVALID;
     const auto t0 = clk::now();
+    const double h2d = e->timing.h2d_ms;
     e->timing = lacx_timing{};
-    int rc = lacx_analyze_device(e, d_left, d_right, frames, stream, nullptr, nullptr);
+    e->timing.h2d_ms = h2d;
+    int rc = prepare(e, d_left, frames);
     if (rc) return rc;
-    rc = emit_shard(e, h_left, d_right ? h_right : nullptr, frames, e->h_bplans, e->h_plans, payload, payload_size,
-                    table, nblocks);
+    const uint32_t nb = blocks_for(frames);
+    uint8_t* buf = nullptr;
+    uint64_t pay = 0;
+    std::vector<uint64_t> offsets;
+    rc = encode_pipelined(e, d_left, d_right, h_left, d_right ? h_right : nullptr, frames,
+                          static_cast<hipStream_t>(stream), 0, &buf, &pay, offsets);
+    if (rc) return rc;
+    uint32_t* tab = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * 2 * (nb ? nb : 1)));
+    if (!tab) {
+        std::free(buf);
+        return fail(e, LACX_E_RUNTIME, "out of memory");
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        tab[2 * b] = e->h_bplans[b].frames;
+        tab[2 * b + 1] = (uint32_t)(offsets[b + 1] - offsets[b]);
+    }
+    *payload = buf;
+    *payload_size = pay;
+    *table = tab;
+    *nblocks = nb;
     e->timing.total_ms = ms_since(t0);
-    return rc;
+    e->timing.emit_ms = e->timing.total_ms - e->timing.d2h_ms;
+    return LACX_OK;
 }
 
 int lacx_encode_shard(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames,
                       uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
     if (!e) return LACX_E_INVALID;
-    int rc = validate_stream_args(e, left, frames);
+    e->timing = lacx_timing{};
+    int rc = prepare(e, left, frames);
     if (rc) return rc;
-    rc = ensure_device(e);
-    if (rc) return rc;
-    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     rc = upload(e, left, right, frames);
     if (rc) return rc;
     return lacx_encode_shard_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr,
@@ -533,7 +702,7 @@ static int block_analyze(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
     HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     rc = upload(e, pcm, nullptr, n);
     if (rc) return rc;
-    return analyze_on_device(e, e->d_left, nullptr, n, 1, 0, /*bit_depth=*/0, e->stream);
+    return analyze_on_device(e, e->d_left, nullptr, n, 1, 0, /*bit_depth=*/0, e->stream[0]);
 }
 
 int lacx_block_plan_only(lacx_encoder* e, const int32_t* pcm, uint32_t n, lacx_channel_plan* plan) {

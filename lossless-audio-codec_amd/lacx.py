@@ -74,6 +74,8 @@ class Timing(C.Structure):
         ("total_ms", C.c_double),
         ("full_slots", C.c_uint64),
         ("probe_slots", C.c_uint64),
+        ("full_launches", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -283,7 +285,9 @@ class Encoder:
             _raise(h, rc)
 
     def encode_shard_device(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
-                            stream: int = 0):
+                            stream: int = 0, copy: bool = True):
+        """Shard encode of device-resident PCM. With copy=False the payload comes back as a zero-copy
+        `Payload` view of the library's buffer (freed when the object dies)."""
         hl, hlp = _i32(h_left)
         hrp = None
         if h_right is not None:
@@ -300,7 +304,34 @@ class Encoder:
             _raise(h, rc)
         table = np.ctypeslib.as_array(tab, shape=(nb.value, 2)).copy()
         lib().lacx_free(tab)
+        if not copy:
+            return Payload(pay, psize.value), table
         return _take(pay, psize), table
+
+
+class Payload:
+    """Zero-copy view of a malloc'd library buffer."""
+
+    def __init__(self, ptr, size):
+        self._ptr = ptr
+        self.size = size
+
+    def __len__(self):
+        return self.size
+
+    def array(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self._ptr, shape=(self.size,)) if self.size else np.zeros(0, np.uint8)
+
+    def tobytes(self) -> bytes:
+        return C.string_at(self._ptr, self.size)
+
+    def __del__(self):
+        try:
+            if self._ptr is not None:
+                lib().lacx_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
 
 
 def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:
