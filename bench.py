@@ -79,7 +79,10 @@ def main():
 
     enc = lacx.Encoder(12, STEREO_MODE, SAMPLE_RATE, BIT_DEPTH, device=local_rank)
     host_cores = os.cpu_count() or 1
-    enc.set_thread_count(max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    # host emit workers: the box's CPU share per GPU (16), overridable for tuning
+    share = max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    emit_threads = int(os.environ.get("LACX_EMIT_THREADS", "0")) or min(16, share)
+    enc.set_thread_count(emit_threads)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -159,7 +162,7 @@ def main():
     # ---- CPU baseline: the unmodified reference (oracle/_ref) on this box's host cores ----------
     cpu = None
     if not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        cores = emit_threads  # same CPU share as the GPU path's host emit
         try:
             import refshim
 
@@ -205,6 +208,7 @@ def main():
                         "16384-frame blocks, zero-run + partitioning on (BASELINE configs[1])",
             "frames_per_gpu": int(frames),
             "blocks_per_gpu": int(b1 - b0),
+            "host_emit_threads": emit_threads,
             "timed_region": "device analysis (PCM resident in HBM) + plan D2H + host emit + shard table"
                             + (" + RCCL all_gather of shard sizes" if world > 1 else ""),
         },

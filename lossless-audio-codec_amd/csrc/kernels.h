@@ -14,6 +14,8 @@ struct DeviceWorkspace {
     uint32_t* need_full = nullptr;  // [num_blocks]
     int64_t* acorr = nullptr;       // [num_blocks][kSlotsPerBlock][13]
     LpcSet* lpcs = nullptr;         // [num_blocks][kSlotsPerBlock]
+    unsigned long long* sums = nullptr;  // [num_blocks][12] stereo proxy sums
+    uint32_t* badidx = nullptr;     // [num_blocks][2] first out-of-range sample per channel
 };
 
 // Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).

@@ -1,9 +1,10 @@
 // kernels.hip -- CDNA4 (gfx950) kernels of the LAC block-encode analysis path.
 //
 // Pipeline per shard of 16384-frame blocks (all launches asynchronous on one stream):
-//   k_ingest    one workgroup per block: sample-range validation, estimate_stereo_mode, exact 13-lag
-//               int64 autocorrelation for every slot (L,R,M,S x {whole block, 3 probe windows})
-//               -> BlockPlan, need masks, acorr[]          (ref lac/encoder.cpp:82-102,126-197; lpc.cpp:80-96)
+//   k_ingest    one workgroup per (block, channel): sample-range validation, the proxy sums of
+//               estimate_stereo_mode, exact 13-lag int64 autocorrelation of the whole block and of the
+//               3 probe windows                             (ref lac/encoder.cpp:82-102,126-178; lpc.cpp:80-96)
+//   k_stereo    one lane per block: LR/MS estimate -> BlockPlan, need masks (ref lac/encoder.cpp:179-196)
 //   k_levinson  one lane per slot: Levinson-Durbin in software x87 extended precision -> Q15 sets
 //                                                           (ref lpc.cpp:98-186)
 //   k_analyze<4,64>     one wave per probe slot of an "uncertain" block (ref lac/encoder.cpp:341-354)
@@ -234,7 +235,13 @@ __device__ __forceinline__ SlotSrc slot_src(const int32_t* L, const int32_t* R, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ingest
+// k_ingest: one workgroup per (block, channel in L,R,M,S)
+//   * coalesced loads of the channel (M/S derived on the fly) into LDS tiles of 1024 samples + 12 of
+//     history, 13-lag exact int64 autocorrelation of the whole block from the tiles (lpc.cpp:80-96);
+//   * the three 256-frame probe windows (lac/encoder.cpp:343-346) as three more small passes;
+//   * the channel's three proxy sums of estimate_stereo_mode (lac/encoder.cpp:146-178) and the sample
+//     range validation (lac/encoder.cpp:82-102).
+// k_stereo: one lane per block turns the 12 sums into the LR/MS estimate + need masks.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t zz64(int64_t v) {  // ref lac/encoder.cpp:38-41
     return v >= 0 ? ((uint64_t)v << 1) : ((((uint64_t)(-(v + 1))) << 1) | 1u);
@@ -249,151 +256,193 @@ __device__ __forceinline__ uint64_t approx_rice_bits(uint64_t sum, uint64_t coun
 }
 
 constexpr int kIngestThreads = 256;
+constexpr int kIngestTile = 1024;
+
+__device__ __forceinline__ bool slot_channel_used(const AnalyzeParams& prm, int ch) {
+    if (prm.channels == 1) return ch == 0;
+    if (prm.stereo_mode == 0) return ch < 2;
+    if (prm.stereo_mode == 1) return ch >= 2;
+    return true;
+}
+
+// Block-wide sum of 13 per-thread int64 partials into out[13] (global), via wave shuffles + LDS atomics.
+__device__ __forceinline__ void reduce13(const int64_t* acc, unsigned long long* s_ac, int64_t* out, int tid) {
+    if (tid < 13) s_ac[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const uint64_t t = wave_sum_u64((uint64_t)acc[k]);
+        if ((tid & 63) == 0) atomicAdd(&s_ac[k], (unsigned long long)t);
+    }
+    __syncthreads();
+    if (tid < 13) out[tid] = (int64_t)s_ac[tid];
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __restrict__ L,
                                                            const int32_t* __restrict__ R, AnalyzeParams prm,
-                                                           BlockPlan* __restrict__ bplans,
-                                                           uint32_t* __restrict__ need_probe,
-                                                           uint32_t* __restrict__ need_full,
+                                                           unsigned long long* __restrict__ sums,
+                                                           uint32_t* __restrict__ badidx,
                                                            int64_t* __restrict__ acorr) {
-    __shared__ unsigned long long s_sums[12];
+    __shared__ int32_t s_tile[12 + kIngestTile];
     __shared__ unsigned long long s_ac[13];
+    __shared__ unsigned long long s_sum[3];
     __shared__ unsigned int s_bad;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = blockIdx.x >> 2;
+    const int ch = (int)(blockIdx.x & 3u);
+    if (!slot_channel_used(prm, ch)) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nb = block_frames(prm, blk);
     const int64_t bstart = (int64_t)blk * kMaxBlock;
-    const bool stereo = prm.channels == 2;
-    if (tid < 12) s_sums[tid] = 0;
+    const SlotSrc src = slot_src(L, R, ch);
+    const bool est = prm.channels == 2 && prm.stereo_mode == 2;
+    const bool validate = ch < 2 && prm.bit_depth != 0;
+    const int32_t lo = prm.bit_depth == 16 ? -32768 : -0x800000;
+    const int32_t hi = prm.bit_depth == 16 ? 32767 : 0x7FFFFF;
+    if (tid < 3) s_sum[tid] = 0;
     if (tid == 0) s_bad = 0xFFFFFFFFu;
+    if (tid < 12) s_tile[tid] = 0;  // history before the block start counts as absent (lags start at n = k)
     __syncthreads();
 
-    // pass 1: range validation (+ the 12 proxy sums of estimate_stereo_mode for per-block stereo)
-    {
-        const int32_t lo = prm.bit_depth == 16 ? -32768 : (prm.bit_depth == 24 ? -0x800000 : INT32_MIN);
-        const int32_t hi = prm.bit_depth == 16 ? 32767 : (prm.bit_depth == 24 ? 0x7FFFFF : INT32_MAX);
-        uint64_t sums[12];
+    int64_t acc[13];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) sums[i] = 0;
-        uint32_t bad = 0xFFFFFFFFu;
-        const bool est = stereo && prm.stereo_mode == 2;
-        for (uint32_t i = tid; i < nb; i += kIngestThreads) {
-            const int64_t l = L[bstart + i];
-            const int64_t r = stereo ? R[bstart + i] : 0;
-            if (l < lo || l > hi) bad = bad < i ? bad : i;
-            if (stereo && (r < lo || r > hi)) bad = bad < (i | 0x80000000u) ? bad : (i | 0x80000000u);
-            if (est) {
-                const int64_t m = (l + r) >> 1, s = l - r;
-                int64_t pl = 0, pr = 0, pm = 0, ps = 0;
-                if (i > 0) {
-                    pl = L[bstart + i - 1];
-                    pr = R[bstart + i - 1];
-                    pm = (pl + pr) >> 1;
-                    ps = pl - pr;
-                }
-                const int64_t cur[4] = {l, r, m, s};
-                const int64_t prev[4] = {pl, pr, pm, ps};
+    for (int k = 0; k < 13; ++k) acc[k] = 0;
+    uint64_t sraw = 0, sdif = 0, sant = 0;
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < nb; base += kIngestTile) {
+        // stage samples [base, base + tile) behind 12 samples of history
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint64_t raw = zz64(cur[c]);
-                    sums[c] += raw;
-                    sums[4 + c] += (i == 0) ? raw : zz64(cur[c] - prev[c]);
-                    sums[8 + c] += (i == 0) ? raw : zz64(cur[c] + prev[c]);
-                }
+        for (int q = 0; q < kIngestTile / kIngestThreads; ++q) {
+            const uint32_t i = base + (uint32_t)(q * kIngestThreads + tid);
+            int32_t v = 0;
+            if (i < nb) {
+                v = slot_fetch(src, bstart + i);
+                if (validate && (v < lo || v > hi)) bad = bad < i ? bad : i;
             }
-        }
-        if (est) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const uint64_t t = wave_sum_u64(sums[i]);
-                if (lane == 0) atomicAdd(&s_sums[i], (unsigned long long)t);
-            }
-        }
-        // first bad sample: left channel wins over right at the same index (left is validated first)
-        if (bad != 0xFFFFFFFFu) atomicMin(&s_bad, bad);
-    }
-
-    // pass 2: autocorrelation of every defined slot
-    for (int slot = 0; slot < kSlotsPerBlock; ++slot) {
-        const SlotGeom g = slot_geom(prm, blk, slot);
-        if (!g.defined) continue;  // uniform
-        if (slot >= 4 && !(stereo && prm.stereo_mode == 2)) continue;
-        const int ch = slot & 3;
-        if (slot < 4 && stereo) {
-            if (prm.stereo_mode == 0 && ch >= 2) continue;
-            if (prm.stereo_mode == 1 && ch < 2) continue;
-        }
-        if (tid < 13) s_ac[tid] = 0;
-        __syncthreads();
-        const SlotSrc src = slot_src(L, R, ch);
-        int64_t acc[13];
-#pragma unroll
-        for (int k = 0; k < 13; ++k) acc[k] = 0;
-        for (uint32_t i = tid; i < g.n; i += kIngestThreads) {
-            const int64_t x0 = slot_fetch(src, g.start + i);
-#pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                if (i >= (uint32_t)k) acc[k] += x0 * (int64_t)slot_fetch(src, g.start + i - k);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            const uint64_t t = wave_sum_u64((uint64_t)acc[k]);
-            if (lane == 0) atomicAdd(&s_ac[k], (unsigned long long)t);
+            s_tile[12 + q * kIngestThreads + tid] = v;
         }
         __syncthreads();
-        if (tid < 13) acorr[((size_t)blk * kSlotsPerBlock + slot) * 13 + tid] = (int64_t)s_ac[tid];
+#pragma unroll
+        for (int q = 0; q < kIngestTile / kIngestThreads; ++q) {
+            const int li = 12 + q * kIngestThreads + tid;
+            const uint32_t i = base + (uint32_t)(q * kIngestThreads + tid);
+            if (i < nb) {
+                const int64_t x0 = s_tile[li];
+#pragma unroll
+                for (int k = 0; k < 13; ++k) {
+                    // lag k pairs x[i] with x[i-k]; samples before the block start are excluded (n >= k)
+                    const int64_t xk = (i >= (uint32_t)k) ? (int64_t)s_tile[li - k] : 0;
+                    acc[k] += x0 * xk;
+                }
+                if (est) {
+                    const uint64_t raw = zz64(x0);
+                    const int64_t prev = s_tile[li - 1];
+                    sraw += raw;
+                    sdif += (i == 0) ? raw : zz64(x0 - prev);
+                    sant += (i == 0) ? raw : zz64(x0 + prev);
+                }
+            }
+        }
+        __syncthreads();
+        // carry the last 12 samples of the tile over as history of the next one
+        if (tid < 12) s_tile[tid] = s_tile[kIngestTile + tid];
         __syncthreads();
     }
+    reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + ch) * 13, tid);
 
+    // probe windows (per-block stereo, blocks above the full-comparison limit only)
+    if (est && nb > (uint32_t)kFullCompareLimit) {
+        for (int w = 1; w <= 3; ++w) {
+            const SlotGeom g = slot_geom(prm, blk, w * 4 + ch);
+#pragma unroll
+            for (int k = 0; k < 13; ++k) acc[k] = 0;
+            if (tid < kProbe) {
+                const int64_t x0 = slot_fetch(src, g.start + tid);
+#pragma unroll
+                for (int k = 0; k < 13; ++k) {
+                    if (tid >= k) acc[k] += x0 * (int64_t)slot_fetch(src, g.start + tid - k);
+                }
+            }
+            reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + w * 4 + ch) * 13, tid);
+        }
+    }
+
+    if (est) {
+        const uint64_t t0 = wave_sum_u64(sraw), t1 = wave_sum_u64(sdif), t2 = wave_sum_u64(sant);
+        if (lane == 0) {
+            atomicAdd(&s_sum[0], (unsigned long long)t0);
+            atomicAdd(&s_sum[1], (unsigned long long)t1);
+            atomicAdd(&s_sum[2], (unsigned long long)t2);
+        }
+    }
+    if (bad != 0xFFFFFFFFu) atomicMin(&s_bad, bad);
+    __syncthreads();
     if (tid == 0) {
-        BlockPlan bp;
-        bp.choose_ms = 0;
-        bp.uncertain = 0;
-        bp.est_ms = 0;
-        bp.invalid = s_bad != 0xFFFFFFFFu;
-        bp.frames = nb;
-        bp.first_bad = s_bad;
-        bp.pad = 0;
-        uint32_t nprobe = 0, nfull = 0;
-        if (!stereo) {
-            nfull = 1u;
-        } else if (prm.stereo_mode == 0) {
-            nfull = 0x3u;
-        } else if (prm.stereo_mode == 1) {
-            nfull = 0xCu;
-            bp.choose_ms = 1;
-        } else {
-            // estimate_channel_proxy_cost + decision: ref lac/encoder.cpp:114-124, 179-196
-            uint64_t bits[4];
-            bool active = false;
-            for (int c = 0; c < 4; ++c) {
-                const uint64_t raw = approx_rice_bits(s_sums[c], nb);
-                const uint64_t dif = approx_rice_bits(s_sums[4 + c], nb);
-                const uint64_t ant = approx_rice_bits(s_sums[8 + c], nb);
-                uint64_t mn = raw < dif ? raw : dif;
-                if (ant < mn) mn = ant;
-                bits[c] = mn;
-                active = active || (raw < dif) || (ant < dif);
-            }
-            const uint64_t lr = bits[0] + bits[1], ms = bits[2] + bits[3];
-            const uint64_t smaller = lr < ms ? lr : ms;
-            const uint64_t diff = lr >= ms ? lr - ms : ms - lr;
-            bp.est_ms = ms < lr;
-            bp.choose_ms = bp.est_ms;
-            bp.uncertain = smaller == 0 || diff == 0 || active || diff <= smaller / 100u;
-            if (!bp.uncertain) {
-                nfull = bp.est_ms ? 0xCu : 0x3u;
-            } else if (nb <= (uint32_t)kFullCompareLimit) {
-                nfull = 0xFu;  // encode both, compare sizes (k_decide phase 2)
-            } else {
-                nprobe = 0xFFF0u;  // 12 probe slots; the whole-block pair is picked by k_decide phase 1
-            }
+        if (est) {
+            sums[(size_t)blk * 12 + ch] = s_sum[0];
+            sums[(size_t)blk * 12 + 4 + ch] = s_sum[1];
+            sums[(size_t)blk * 12 + 8 + ch] = s_sum[2];
         }
-        bplans[blk] = bp;
-        need_probe[blk] = nprobe;
-        need_full[blk] = nfull;
+        if (ch < 2) badidx[blk * 2 + ch] = s_bad;
     }
+}
+
+__global__ __launch_bounds__(64) void k_stereo(AnalyzeParams prm, const unsigned long long* __restrict__ sums,
+                                               const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
+                                               uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
+    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= prm.num_blocks) return;
+    const uint32_t nb = block_frames(prm, blk);
+    const bool stereo = prm.channels == 2;
+    BlockPlan bp;
+    bp.choose_ms = 0;
+    bp.uncertain = 0;
+    bp.est_ms = 0;
+    // first bad sample in the reference's order: the left channel is validated before the right one
+    const uint32_t badl = badidx[blk * 2], badr = stereo ? badidx[blk * 2 + 1] : 0xFFFFFFFFu;
+    bp.invalid = (badl != 0xFFFFFFFFu) || (badr != 0xFFFFFFFFu);
+    bp.first_bad = (badl != 0xFFFFFFFFu) ? badl : (badr != 0xFFFFFFFFu ? (badr | 0x80000000u) : 0xFFFFFFFFu);
+    bp.frames = nb;
+    bp.pad = 0;
+    uint32_t nprobe = 0, nfull = 0;
+    if (!stereo) {
+        nfull = 1u;
+    } else if (prm.stereo_mode == 0) {
+        nfull = 0x3u;
+    } else if (prm.stereo_mode == 1) {
+        nfull = 0xCu;
+        bp.choose_ms = 1;
+    } else {
+        // estimate_channel_proxy_cost + decision: ref lac/encoder.cpp:114-124, 179-196
+        const unsigned long long* s = sums + (size_t)blk * 12;
+        uint64_t bits[4];
+        bool active = false;
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t raw = approx_rice_bits(s[c], nb);
+            const uint64_t dif = approx_rice_bits(s[4 + c], nb);
+            const uint64_t ant = approx_rice_bits(s[8 + c], nb);
+            uint64_t mn = raw < dif ? raw : dif;
+            if (ant < mn) mn = ant;
+            bits[c] = mn;
+            active = active || (raw < dif) || (ant < dif);
+        }
+        const uint64_t lr = bits[0] + bits[1], ms = bits[2] + bits[3];
+        const uint64_t smaller = lr < ms ? lr : ms;
+        const uint64_t diff = lr >= ms ? lr - ms : ms - lr;
+        bp.est_ms = ms < lr;
+        bp.choose_ms = bp.est_ms;
+        bp.uncertain = smaller == 0 || diff == 0 || active || diff <= smaller / 100u;
+        if (!bp.uncertain) {
+            nfull = bp.est_ms ? 0xCu : 0x3u;
+        } else if (nb <= (uint32_t)kFullCompareLimit) {
+            nfull = 0xFu;  // encode both, compare sizes (k_decide phase 2)
+        } else {
+            nprobe = 0xFFF0u;  // 12 probe slots; the whole-block pair is picked by k_decide phase 1
+        }
+    }
+    bplans[blk] = bp;
+    need_probe[blk] = nprobe;
+    need_full[blk] = nfull;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,8 +774,10 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     if (ev) (void)hipEventRecord(ev[0], stream);
     e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ingest, dim3(nb), dim3(kIngestThreads), 0, stream, d_left, d_right, prm, ws.bplans,
-                       ws.need_probe, ws.need_full, ws.acorr);
+    hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, d_left, d_right, prm, ws.sums,
+                       ws.badidx, ws.acorr);
+    hipLaunchKernelGGL(k_stereo, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, ws.sums, ws.badidx, ws.bplans,
+                       ws.need_probe, ws.need_full);
     hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + 63) / 64), dim3(64), 0, stream, prm, ws.acorr,
                        ws.lpcs);
     if (ev) (void)hipEventRecord(ev[1], stream);

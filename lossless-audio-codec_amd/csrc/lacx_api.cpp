@@ -3,7 +3,7 @@
 // Thin host layer: owns the HIP streams, the device workspace and pinned plan buffers, enqueues the
 // kernels (kernels.hip), and runs the host emit (emit.cpp) from the returned plan records.
 // Encode calls are pipelined: the stream is cut into chunks of blocks whose kernels alternate between
-// two HIP streams; as soon as a chunk's plan records have landed in pinned host memory the emit
+// a few HIP streams; as soon as a chunk's plan records have landed in pinned host memory the emit
 // workers start on its blocks while the GPU analyses the next chunk.
 // There is no CPU analysis path here: without a usable HIP device every analysing call fails.
 #include <hip/hip_runtime_api.h>
@@ -28,7 +28,7 @@ static_assert(sizeof(lacx_block_plan) == sizeof(BlockPlan), "ABI block plan layo
 static_assert(sizeof(ChannelPlan) == 296, "ChannelPlan layout");
 
 namespace {
-constexpr int kStreams = 2;
+constexpr int kStreams = 4;
 constexpr int kMaxChunks = 16;
 constexpr uint32_t kMinChunkBlocks = 192;  // >= 1.5 rounds of 1024-thread workgroups over 256 CUs
 }  // namespace
@@ -108,6 +108,8 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.need_full) (void)hipFree(e->ws.need_full);
     if (e->ws.acorr) (void)hipFree(e->ws.acorr);
     if (e->ws.lpcs) (void)hipFree(e->ws.lpcs);
+    if (e->ws.sums) (void)hipFree(e->ws.sums);
+    if (e->ws.badidx) (void)hipFree(e->ws.badidx);
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -122,6 +124,8 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.need_full, (size_t)nblocks * 4), "hipMalloc(need)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.acorr, slots * 13 * sizeof(int64_t)), "hipMalloc(acorr)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.lpcs, slots * sizeof(LpcSet)), "hipMalloc(lpcs)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.sums, (size_t)nblocks * 12 * sizeof(unsigned long long)), "hipMalloc(sums)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.badidx, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(badidx)");
         e->ws_blocks = nblocks;
     }
     if (nblocks > e->h_blocks) {
@@ -192,6 +196,8 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
     w.need_full += first_block;
     w.acorr += s * 13;
     w.lpcs += s;
+    w.sums += (size_t)first_block * 12;
+    w.badidx += (size_t)first_block * 2;
     return w;
 }
 
@@ -202,6 +208,10 @@ struct Chunk {
 std::vector<Chunk> plan_chunks(uint32_t nb) {
     uint32_t nchunks = nb / kMinChunkBlocks;
     nchunks = std::max(1u, std::min(nchunks, 8u));
+    if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
+        const unsigned long v = std::strtoul(env, nullptr, 0);
+        if (v >= 1 && v <= (unsigned long)kMaxChunks) nchunks = std::min<uint32_t>((uint32_t)v, nb);
+    }
     const uint32_t per = (nb + nchunks - 1) / nchunks;
     std::vector<Chunk> out;
     for (uint32_t f = 0; f < nb; f += per) out.push_back({f, std::min(per, nb - f)});
@@ -332,7 +342,9 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
     reset_device_timing(e);
     const auto t0 = clk::now();
     // the caller's stream (if any) carries chunks 0, 2, ...; the encoder's second stream the others
-    hipStream_t st[kStreams] = {user_stream ? user_stream : e->stream[0], e->stream[1]};
+    hipStream_t st[kStreams];
+    for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
+    if (user_stream) st[0] = user_stream;
     for (size_t c = 0; c < chunks.size(); ++c) {
         rc = enqueue_chunk(e, d_left, d_right, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, chunks[c],
                            (int)c, st[c % kStreams]);
