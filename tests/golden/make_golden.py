@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Mints the golden fixtures from the UNMODIFIED reference (oracle/_ref/liblac_ref.so, built in place
+from /root/reference by oracle/Makefile).  Run in the build container only:
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Outputs (committed): tests/golden/small/*.lac   tiny complete .lac files for byte-for-byte diffs
+                     tests/golden/digests.json  sha256 + length of the reference's .lac for seeded
+                                                synthetic inputs (regenerated bit-exactly by synth.py)
+Fixtures are data only: inputs are described by generator parameters, outputs are the reference's bytes.
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import __graft_entry__ as ge  # noqa: E402
+import refshim  # noqa: E402
+
+synth = ge.load_pkg().synth
+
+SMALL = [
+    # name, frames, channels, bit_depth, rate, stereo_mode, kind, stereo, seed
+    ("one_frame_st16", 1, 2, 16, 48000, 2, "noise", "wide", 1),
+    ("n31_st24", 31, 2, 24, 96000, 2, "music", "wide", 2),
+    ("n32_st16", 32, 2, 16, 44100, 2, "music", "narrow", 3),
+    ("n33_mono16", 33, 1, 16, 48000, 0, "tone", "wide", 4),
+    ("n255_st16", 255, 2, 16, 48000, 2, "walk", "wide", 5),
+    ("n256_st24", 256, 2, 24, 192000, 2, "noise", "independent", 6),
+    ("n257_st16_ms", 257, 2, 16, 48000, 1, "music", "wide", 7),
+    ("n2400_mono16_selftest", 2400, 1, 16, 48000, 0, "tone", "wide", 8),  # BASELINE configs[0] shape
+    ("n4095_st16", 4095, 2, 16, 48000, 2, "noise", "independent", 9),
+    ("n4096_st16", 4096, 2, 16, 48000, 2, "mixed", "wide", 10),
+    ("n4097_st16", 4097, 2, 16, 48000, 2, "noise", "independent", 11),
+    ("n16421_st16", 16384 + 37, 2, 16, 48000, 2, "mixed", "wide", 12),
+    ("n16421_st24_lr", 16384 + 37, 2, 24, 96000, 0, "music", "wide", 13),
+    ("silence_st16", 20000, 2, 16, 48000, 2, "silence", "identical", 14),
+    ("sparse_mono24", 9000, 1, 24, 48000, 0, "sparse", "wide", 15),
+]
+
+DIGESTS = [
+    # name, frames, channels, bit_depth, rate, stereo_mode, kind, stereo, seed, cpu_test, gpu_test
+    ("cfg2_10min_st16_48k_auto", 28_800_000, 2, 16, 48000, 2, "music", "wide", 2026, False, True),
+    ("cfg2_60s_st16_48k_auto", 2_880_000, 2, 16, 48000, 2, "music", "wide", 2026, True, True),
+    ("cfg3_60s_st24_96k_mixed", 5_760_000, 2, 24, 96000, 2, "mixed", "wide", 7, True, True),
+    ("noise_20s_st16_48k", 960_000, 2, 16, 48000, 2, "noise", "independent", 3, True, True),
+    ("mono_30s_16_44k", 1_323_000, 1, 16, 44100, 0, "mixed", "wide", 5, True, True),
+    ("forced_ms_20s_24_192k", 3_840_000, 2, 24, 192000, 1, "music", "narrow", 9, False, True),
+    ("forced_lr_20s_16_96k", 1_920_000, 2, 16, 96000, 0, "mixed", "wide", 11, False, True),
+]
+
+
+def main():
+    if not refshim.available():
+        raise SystemExit("oracle/_ref/liblac_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    os.makedirs(os.path.join(HERE, "small"), exist_ok=True)
+    index = []
+    for name, frames, ch, bd, sr, sm, kind, st, seed in SMALL:
+        left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st)
+        data = refshim.encode(left, right, sr, bd, sm)
+        with open(os.path.join(HERE, "small", name + ".lac"), "wb") as f:
+            f.write(data)
+        index.append(dict(name=name, stereo_mode=sm, lac_bytes=len(data), lac_sha256=hashlib.sha256(data).hexdigest(),
+                          gen=dict(frames=frames, channels=ch, bit_depth=bd, sample_rate=sr, seed=seed, kind=kind,
+                                   stereo=st)))
+        print(name, len(data))
+    with open(os.path.join(HERE, "small", "index.json"), "w") as f:
+        json.dump(index, f, indent=1)
+    out = []
+    for name, frames, ch, bd, sr, sm, kind, st, seed, cpu_test, gpu_test in DIGESTS:
+        left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st)
+        data = refshim.encode(left, right, sr, bd, sm)
+        out.append(dict(name=name, stereo_mode=sm, lac_bytes=len(data), lac_sha256=hashlib.sha256(data).hexdigest(),
+                        cpu_test=cpu_test, gpu_test=gpu_test,
+                        gen=dict(frames=frames, channels=ch, bit_depth=bd, sample_rate=sr, seed=seed, kind=kind,
+                                 stereo=st)))
+        print(name, len(data), out[-1]["lac_sha256"][:16])
+    with open(os.path.join(HERE, "digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

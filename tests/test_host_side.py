@@ -1,0 +1,114 @@
+"""Host-side product code without a GPU: the C ABI surface, the bit emit + container writer driven by
+oracle-derived plans, error behaviour when no device is present, shard assembly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "lacx.h")).read()
+    declared = set(re.findall(r"\b(lacx_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 16
+    lib = pkg.lacx.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/lacx.h but not exported by liblacx.so"
+    assert set(pkg.lacx.EXPORTS) <= declared
+
+
+def _oracle_plans(pkg, oracle, left, right, sm, zr=True, pt=True):
+    lacx = pkg.lacx
+    n = left.size
+    nb = (n + 16383) // 16384
+    bplans = (lacx.BlockPlan * nb)()
+    plans = (lacx.ChannelPlan * (nb * 16))()
+
+    def fill(dst, x):
+        op = oracle.block_plan(x, zr, pt)
+        dst.predictor_type, dst.order, dst.partition_order, dst.valid = op.predictor_type, op.order, op.partition_order, 1
+        for i in range(12):
+            dst.coef[i] = op.coeffs_q15[i + 1]
+        dst.total_bits = op.total_bits
+        dst.payload_bytes = len(oracle.block_encode(x, zr, pt))
+        for i in range(op.part_count):
+            dst.part_mode_k[i] = (op.part_mode[i] << 5) | op.part_k[i]
+
+    for b in range(nb):
+        l = left[b * 16384:(b + 1) * 16384]
+        bplans[b].frames = l.size
+        if right is None:
+            fill(plans[b * 16], l)
+            continue
+        r = right[b * 16384:(b + 1) * 16384]
+        m = ((l.astype(np.int64) + r) >> 1).astype(np.int32)
+        s = (l - r).astype(np.int32)
+        chans = [l, r, m, s]
+        size = lambda x: len(oracle.block_encode(x, zr, pt))  # noqa: E731
+        if sm in (0, 1):
+            ms = sm
+        else:
+            st = oracle.stereo_estimate(l, r)
+            ms = st.choose_ms
+            if st.uncertain:
+                if l.size <= 4096:
+                    ms = int(size(m) + size(s) < size(l) + size(r))
+                else:
+                    starts = [0, (l.size - 256) // 2, l.size - 256]
+                    lr = sum(size(c[a:a + 256]) for a in starts for c in (l, r))
+                    mss = sum(size(c[a:a + 256]) for a in starts for c in (m, s))
+                    ms = int(mss < lr)
+        bplans[b].choose_ms = ms
+        for c in ((2, 3) if ms else (0, 1)):
+            fill(plans[b * 16 + c], chans[c])
+    return bplans, plans
+
+
+@pytest.mark.parametrize("case", [(16, 48000, "music", 2, 2), (24, 96000, "mixed", 2, 2), (16, 48000, "noise", 2, 2),
+                                  (16, 44100, "mixed", 1, 0), (24, 192000, "mixed", 2, 1), (16, 48000, "mixed", 2, 0)])
+def test_host_emit_and_container_from_plans(pkg, oracle, case):
+    bd, sr, kind, ch, sm = case
+    left, right = pkg.synth.synth_pcm(16384 * 3 + 4001, ch, bd, sr, seed=5, kind=kind)
+    bplans, plans = _oracle_plans(pkg, oracle, left, right, sm)
+    enc = pkg.lacx.Encoder(12, sm, sr, bd)
+    enc.set_thread_count(3)
+    got = enc.emit_from_plans(left, right, bplans, plans)
+    assert got == oracle.encode(left, right, sr, bd, sm, threads=4)
+
+
+def test_emit_rejects_inconsistent_plan(pkg, oracle):
+    left, right = pkg.synth.synth_pcm(16384 + 10, 2, 16, 48000, seed=2, kind="music")
+    bplans, plans = _oracle_plans(pkg, oracle, left, right, 2)
+    plans[0 if not bplans[0].choose_ms else 2].payload_bytes += 1
+    with pytest.raises(RuntimeError):
+        pkg.lacx.Encoder(12, 2, 48000, 16).emit_from_plans(left, right, bplans, plans)
+
+
+def test_no_device_means_loud_failure_not_fallback(pkg):
+    if pkg.lacx.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    left, right = pkg.synth.synth_pcm(1000, 2, 16, 48000, seed=1, kind="music")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.lacx.Encoder(12, 2, 48000, 16).encode(left, right)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.lacx.BlockEncoder().encode(left)
+    # argument errors come first, exactly like the reference (ref src/codec/lac/encoder.cpp:220-237)
+    with pytest.raises(ValueError, match="unsupported sample rate"):
+        pkg.lacx.Encoder(12, 2, 12345, 16).encode(left, right)
+
+
+def test_assemble_matches_single_stream(pkg, oracle):
+    """Block-range shards (encoded here by the oracle) + lacx_assemble == one-shot stream bytes."""
+    left, right = pkg.synth.synth_pcm(16384 * 5 + 321, 2, 16, 48000, seed=12, kind="mixed")
+    whole = oracle.encode(left, right, 48000, 16, 2, threads=4)
+    nb = int.from_bytes(whole[10:14], "big")
+    table = np.frombuffer(whole[14:14 + 8 * nb], dtype=">u4").reshape(nb, 2).astype(np.uint32)
+    payload = whole[14 + 8 * nb:]
+    offs = [0] + [int(v) for v in np.cumsum(table[:, 1].astype(np.int64))]
+    for cuts in ([2], [1, 4], [1, 2, 3, 4, 5]):
+        bounds = [0] + cuts + [nb]
+        shards = [(payload[offs[a]:offs[b]], table[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+        assert pkg.lacx.assemble(48000, 16, 2, 2, shards) == whole
