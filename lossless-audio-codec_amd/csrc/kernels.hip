@@ -290,13 +290,15 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     __shared__ unsigned int s_bad;
     const uint32_t blk = blockIdx.x >> 2;
     const int ch = (int)(blockIdx.x & 3u);
-    if (!slot_channel_used(prm, ch)) return;  // uniform
+    const bool used = slot_channel_used(prm, ch);
+    // forced mid/side still validates the left/right samples (ref lac/encoder.cpp:238-241)
+    const bool validate = ch < 2 && ch < prm.channels && prm.bit_depth != 0;
+    if (!used && !validate) return;  // uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nb = block_frames(prm, blk);
     const int64_t bstart = (int64_t)blk * kMaxBlock;
     const SlotSrc src = slot_src(L, R, ch);
     const bool est = prm.channels == 2 && prm.stereo_mode == 2;
-    const bool validate = ch < 2 && prm.bit_depth != 0;
     const int32_t lo = prm.bit_depth == 16 ? -32768 : -0x800000;
     const int32_t hi = prm.bit_depth == 16 ? 32767 : 0x7FFFFF;
     if (tid < 3) s_sum[tid] = 0;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
         for (int q = 0; q < kIngestTile / kIngestThreads; ++q) {
             const int li = 12 + q * kIngestThreads + tid;
             const uint32_t i = base + (uint32_t)(q * kIngestThreads + tid);
-            if (i < nb) {
+            if (used && i < nb) {
                 const int64_t x0 = s_tile[li];
 #pragma unroll
                 for (int k = 0; k < 13; ++k) {
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
         if (tid < 12) s_tile[tid] = s_tile[kIngestTile + tid];
         __syncthreads();
     }
-    reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + ch) * 13, tid);
+    if (used) reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + ch) * 13, tid);
 
     // probe windows (per-block stereo, blocks above the full-comparison limit only)
     if (est && nb > (uint32_t)kFullCompareLimit) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
             sums[(size_t)blk * 12 + 4 + ch] = s_sum[1];
             sums[(size_t)blk * 12 + 8 + ch] = s_sum[2];
         }
-        if (ch < 2) badidx[blk * 2 + ch] = s_bad;
+        if (validate || ch < 2) badidx[blk * 2 + ch] = s_bad;
     }
 }
 
