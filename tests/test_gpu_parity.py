@@ -181,3 +181,19 @@ def test_golden_digests(gpu):
         got = enc.encode(left, right)
         assert len(got) == ent["lac_bytes"], ent["name"]
         assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], ent["name"]
+
+
+def test_cpp_mirror_classes_on_device(gpu):
+    import subprocess
+
+    from test_host_side import _build_mirror_test
+
+    assert subprocess.call([_build_mirror_test()]) == 0
+
+
+def test_forced_ms_still_validates_left_right(gpu):
+    left, right = gpu.synth.synth_pcm(16384 + 50, 2, 16, 48000, seed=8, kind="music")
+    bad = left.copy()
+    bad[17000] = 70000
+    with pytest.raises(ValueError, match=r"left sample at index 17000 is outside"):
+        gpu.lacx.Encoder(12, 1, 48000, 16).encode(bad, right)
