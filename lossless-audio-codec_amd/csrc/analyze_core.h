@@ -209,10 +209,11 @@ LACX_HD void thread_init(Thread<G>& th, uint32_t n, int tid) {
 // ---------------------------------------------------------------------------------------------
 template <class G>
 LACX_HD void stage_samples(const Thread<G>& th, Smem<G>& sh, const SlotSrc& src, int64_t start) {
+    int32_t* col = &sh.xp.x[th.tid];
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         const int j = th.a + i;
-        sh.xp.x[i * G::T + th.tid] = ((uint32_t)j < th.n) ? slot_fetch(src, start + j) : 0;
+        col[i * G::T] = ((uint32_t)j < th.n) ? slot_fetch(src, start + j) : 0;
     }
 }
 
@@ -262,11 +263,18 @@ LACX_HD void plane_counts(const uint32_t* u, uint32_t* cs) {
 // ---------------------------------------------------------------------------------------------
 template <class G>
 LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh, int cand) {
+    // x[a-12 .. a+CH): element `el` of chunk tid+co sits at row el, column tid+co of the transposed
+    // image, i.e. at a compile-time offset from one base address (no per-candidate address arithmetic).
     int32_t xh[G::CH + 12];
 #pragma unroll
     for (int i = 0; i < G::CH + 12; ++i) {
-        const int j = th.a - 12 + i;
-        xh[i] = (j >= 0) ? sh.xp.x[sw<G>(j < 0 ? 0 : j)] : 0;
+        const int d = i - 12;
+        const int co = (d >= 0) ? d / G::CH : -((-d + G::CH - 1) / G::CH);
+        const int el = d - co * G::CH;
+        const int tt = th.tid + co;
+        // own base per column so that every row is base + a 16-bit immediate offset
+        const int32_t* col = &sh.xp.x[tt < 0 ? 0 : tt];
+        xh[i] = (tt >= 0) ? col[el * G::T] : 0;
     }
     const int32_t* x = xh + 12;
     uint32_t u[G::CH];
@@ -323,9 +331,10 @@ LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh, int cand) {
 // Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.
 LACX_HD void planes_to_ksums(const uint32_t* C, uint64_t* A, int kmax) {
     uint64_t acc = 0;
+#pragma unroll
     for (int b = 29; b >= 0; --b) {
         acc = (acc << 1) + C[b];
-        if (b <= kmax) A[b] = acc;
+        if (b <= 15) A[b] = (b <= kmax) ? acc : 0;
     }
 }
 
@@ -333,6 +342,7 @@ LACX_HD void planes_to_ksums(const uint32_t* C, uint64_t* A, int kmax) {
 LACX_HD uint32_t pick_initial_k(const uint64_t* A, uint32_t m) {
     uint32_t best_k = 0;
     uint64_t best = ~0ull;
+#pragma unroll
     for (uint32_t k = 0; k <= 12; ++k) {
         const uint64_t c = A[k] + (uint64_t)m * (1u + k);
         if (c < best) {
@@ -347,6 +357,7 @@ LACX_HD uint32_t pick_initial_k(const uint64_t* A, uint32_t m) {
 LACX_HD uint32_t pick_static_k(const uint64_t* A, uint32_t m, uint64_t* bits) {
     uint32_t best_k = 0;
     uint64_t best = ~0ull;
+#pragma unroll
     for (uint32_t k = 0; k <= 15; ++k) {
         const uint64_t c = A[k] + (uint64_t)m * (1u + k);
         if (c < best) {
@@ -511,11 +522,13 @@ LACX_HD void packed_planes(const Thread<G>& th, uint32_t* words /* 15 */) {
 // sum_j (u_j >> k) over [s, e), k = 0..15, from the group prefix table + direct sums at ragged ends.
 template <class G>
 LACX_HD void range_ksums(const Smem<G>& sh, uint32_t s, uint32_t e, uint64_t* A) {
+#pragma unroll
     for (int k = 0; k < 16; ++k) A[k] = 0;
     const uint32_t gs = (s + 63u) >> 6, ge = e >> 6;
     uint32_t e0 = e, s1 = e;  // direct ranges [s, e0) and [s1, e)
     if (gs < ge) {
         uint32_t C[30];
+#pragma unroll
         for (int w = 0; w < 15; ++w) {
             const uint32_t d = sh.xp.part.grp[w][ge] - sh.xp.part.grp[w][gs];
             C[w] = d & 0xFFFFu;
@@ -527,10 +540,12 @@ LACX_HD void range_ksums(const Smem<G>& sh, uint32_t s, uint32_t e, uint64_t* A)
     }
     for (uint32_t j = s; j < e0; ++j) {
         const uint32_t u = sh.u[sw<G>((int)j)];
+#pragma unroll
         for (int k = 0; k < 16; ++k) A[k] += u >> k;
     }
     for (uint32_t j = s1; j < e; ++j) {
         const uint32_t u = sh.u[sw<G>((int)j)];
+#pragma unroll
         for (int k = 0; k < 16; ++k) A[k] += u >> k;
     }
 }

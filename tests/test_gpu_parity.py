@@ -194,6 +194,6 @@ def test_cpp_mirror_classes_on_device(gpu):
 def test_forced_ms_still_validates_left_right(gpu):
     left, right = gpu.synth.synth_pcm(16384 + 50, 2, 16, 48000, seed=8, kind="music")
     bad = left.copy()
-    bad[17000] = 70000
-    with pytest.raises(ValueError, match=r"left sample at index 17000 is outside"):
+    bad[16400] = 70000
+    with pytest.raises(ValueError, match=r"left sample at index 16400 is outside"):
         gpu.lacx.Encoder(12, 1, 48000, 16).encode(bad, right)
