@@ -48,7 +48,10 @@ typedef struct lacx_config {
     uint8_t partitioning_enabled; /* reference default: 1 */
     int32_t device;               /* HIP device ordinal, -1 = current device */
     uint32_t emit_threads;        /* host emit worker threads, 0 = hardware concurrency */
+    uint32_t flags;               /* LACX_FLAG_* */
 } lacx_config;
+
+#define LACX_FLAG_HOST_EMIT 1u /* keep the bit emit on the host (north_star layout); default: device-side emit */
 
 /* Same layout as lacx::ChannelPlan (csrc/lacx_types.h). */
 typedef struct lacx_channel_plan {
@@ -80,7 +83,7 @@ typedef struct lacx_timing {
     double probe_ms;        /* k_analyze<4,64> + k_decide */
     double full_ms;         /* k_analyze<16,1024> (the dominant kernel), summed over its launches */
     double d2h_ms;          /* plan records device -> host, incl. stream sync */
-    double emit_ms;         /* host bit emit + container */
+    double emit_ms;         /* host emit tail after the last plan arrived, or (device emit) the k_emit kernels */
     double total_ms;        /* wall time of the call */
     uint64_t full_slots;    /* workgroups of the dominant kernel that did work */
     uint64_t probe_slots;
@@ -127,6 +130,13 @@ int lacx_encode_shard_device(lacx_encoder* enc, const int32_t* d_left, const int
                              const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
                              uint8_t** payload, uint64_t* payload_size, uint32_t** table,
                              uint32_t* nblocks);
+
+/* Zero-copy variant: *payload / *table point into buffers owned by the encoder (pinned host memory) that
+ * stay valid until the next call on the same encoder. */
+int lacx_encode_shard_device_view(lacx_encoder* enc, const int32_t* d_left, const int32_t* d_right,
+                                  const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                                  const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                                  uint32_t* nblocks);
 
 /* Host-only: header + block table + payload concat of shards given in stream order. */
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,

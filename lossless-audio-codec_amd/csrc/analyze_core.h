@@ -207,8 +207,8 @@ LACX_HD void thread_init(Thread<G>& th, uint32_t n, int tid) {
 // ---------------------------------------------------------------------------------------------
 // sample staging: x[sw(j)] = sample j (0 beyond n)
 // ---------------------------------------------------------------------------------------------
-template <class G>
-LACX_HD void stage_samples(const Thread<G>& th, Smem<G>& sh, const SlotSrc& src, int64_t start) {
+template <class G, class M>
+LACX_HD void stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
     int32_t* col = &sh.xp.x[th.tid];
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
@@ -261,8 +261,8 @@ LACX_HD void plane_counts(const uint32_t* u, uint32_t* cs) {
 // Fixed differences are taken in wrapping 32-bit arithmetic: the true values fit int32 for
 // |x| <= 2^24, so the low 32 bits equal the reference's int64 results.
 // ---------------------------------------------------------------------------------------------
-template <class G>
-LACX_HD void phase_r(Thread<G>& th, Smem<G>& sh, int cand) {
+template <class G, class M>
+LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
     // x[a-12 .. a+CH): element `el` of chunk tid+co sits at row el, column tid+co of the transposed
     // image, i.e. at a compile-time offset from one base address (no per-candidate address arithmetic).
     int32_t xh[G::CH + 12];
@@ -371,8 +371,8 @@ LACX_HD uint32_t pick_static_k(const uint64_t* A, uint32_t m, uint64_t* bits) {
 
 // Phase A: unbiased k after every sample -> micro-window flags into bits 30/31 of u (ref rice.hpp:68-80),
 // and the chunk's packed flag counts.
-template <class G, bool NARROW>
-LACX_HD void phase_a(Thread<G>& th, Smem<G>& sh) {
+template <class G, bool NARROW, class M>
+LACX_HD void phase_a(Thread<G>& th, M& sh) {
     uint64_t P = sh.tabP[th.tid];
     uint32_t cnt = 0;
     uint32_t c = (uint32_t)th.a;
@@ -391,8 +391,8 @@ LACX_HD void phase_a(Thread<G>& th, Smem<G>& sh) {
 
 // Sample j as seen by the zero-run lookahead: its u, or 1 ("not a zero") at/after `limit`.
 // j may run up to 3 past the slot; the read then lands in the words that follow u[] and is discarded.
-template <class G>
-LACX_HD uint32_t peek_u(const Smem<G>& sh, uint32_t j, uint32_t limit) {
+template <class G, class M>
+LACX_HD uint32_t peek_u(const M& sh, uint32_t j, uint32_t limit) {
     const uint32_t idx = (j % (uint32_t)G::CH) * (uint32_t)G::T + (j / (uint32_t)G::CH);
     const uint32_t v = sh.u[idx] & 0x3FFFFFFFu;
     return (j < limit) ? v : 1u;
@@ -420,8 +420,8 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
     uint32_t w0 = sh.u[t];  // own sample incl. flags
-    uint32_t n1 = peek_u(sh, (uint32_t)th.a + 1u, n), n2 = peek_u(sh, (uint32_t)th.a + 2u, n),
-             n3 = peek_u(sh, (uint32_t)th.a + 3u, n);
+    uint32_t n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n), n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n),
+             n3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         if (i >= th.cnt) break;
@@ -451,7 +451,7 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         w0 = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
         n1 = n2;
         n2 = n3;
-        n3 = peek_u(sh, (uint32_t)(th.a + i) + 4u, n);
+        n3 = peek_u<G>(sh, (uint32_t)(th.a + i) + 4u, n);
     }
     th.crice = rice;
     th.cbin = bin;
@@ -599,8 +599,8 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
     uint32_t u = sh.u[th.tid];
-    uint32_t x1 = peek_u(sh, (uint32_t)th.a + 1u, n), x2 = peek_u(sh, (uint32_t)th.a + 2u, n),
-             x3 = peek_u(sh, (uint32_t)th.a + 3u, n);
+    uint32_t x1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n), x2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n),
+             x3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t j = (uint32_t)(th.a + i);
         if (j == e) {  // partition boundary inside the chunk
@@ -636,7 +636,7 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
         u = x1;
         x1 = x2;
         x2 = x3;
-        x3 = peek_u(sh, (uint32_t)(th.a + i) + 4u, n);
+        x3 = peek_u<G>(sh, (uint32_t)(th.a + i) + 4u, n);
     }
     flush(segbase + part, rice, bin, zr, hasrun);
 }
@@ -680,7 +680,7 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     int32_t fg = (int32_t)a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk (not yet clipped to a partition)
     uint32_t P = Pa;
     uint32_t u = sh.u[t];
-    uint32_t x1 = peek_u(sh, a + 1u, n), x2 = peek_u(sh, a + 2u, n), x3 = peek_u(sh, a + 3u, n);
+    uint32_t x1 = peek_u<G>(sh, a + 1u, n), x2 = peek_u<G>(sh, a + 2u, n), x3 = peek_u<G>(sh, a + 3u, n);
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t j = a + (uint32_t)i;
         const bool z = (u == 0);
@@ -712,7 +712,7 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         u = x1;
         x1 = x2;
         x2 = x3;
-        x3 = peek_u(sh, j + 4u, n);
+        x3 = peek_u<G>(sh, j + 4u, n);
     }
 #pragma unroll
     for (int q = 0; q < G::MAXP; ++q) {

@@ -16,6 +16,9 @@ struct DeviceWorkspace {
     LpcSet* lpcs = nullptr;         // [num_blocks][kSlotsPerBlock]
     unsigned long long* sums = nullptr;  // [num_blocks][12] stereo proxy sums
     uint32_t* badidx = nullptr;     // [num_blocks][2] first out-of-range sample per channel
+    unsigned long long* block_off = nullptr;  // [num_blocks + 1] payload byte offsets (device emit)
+    uint32_t* table = nullptr;      // [num_blocks][2] (frames, bytes) block table entries
+    uint32_t* err_flag = nullptr;   // device emit consistency flag
 };
 
 // Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).
@@ -23,6 +26,10 @@ struct DeviceWorkspace {
 // whole-block analysis kernel, end.
 hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                            const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev);
+
+// Device-side emit of the analysed blocks of one chunk into d_payload (k_offsets + k_emit).
+hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
+                       const DeviceWorkspace& ws, uint8_t* d_payload, hipStream_t stream);
 
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "analyze_core.h"
+#include "emit_core.h"
 #include "kernels.h"
 
 namespace lacx {
@@ -65,8 +66,8 @@ struct ScanRegs {
     int32_t z, zinc;
 };
 
-template <class G>
-__device__ __forceinline__ void scan_pz_part1(Smem<G>& sh, int tid, ScanRegs<G>& r) {
+template <class G, class M>
+__device__ __forceinline__ void scan_pz_part1(M& sh, int tid, ScanRegs<G>& r) {
     const int lane = tid & 63, wave = tid >> 6;
     r.v = sh.tabP[tid];
     r.z = sh.tabNZ[tid];
@@ -89,8 +90,8 @@ __device__ __forceinline__ void scan_pz_part1(Smem<G>& sh, int tid, ScanRegs<G>&
     }
 }
 
-template <class G>
-__device__ __forceinline__ void scan_pz_part2(Smem<G>& sh, int tid, const ScanRegs<G>& r) {
+template <class G, class M>
+__device__ __forceinline__ void scan_pz_part2(M& sh, int tid, const ScanRegs<G>& r) {
     const int lane = tid & 63, wave = tid >> 6;
     uint64_t base = 0;
     int32_t zbase = -1;
@@ -109,8 +110,8 @@ __device__ __forceinline__ void scan_pz_part2(Smem<G>& sh, int tid, const ScanRe
     }
 }
 
-template <class G>
-__device__ __forceinline__ uint32_t scan_f_part1(Smem<G>& sh, int tid, uint32_t& own) {
+template <class G, class M>
+__device__ __forceinline__ uint32_t scan_f_part1(M& sh, int tid, uint32_t& own) {
     const int lane = tid & 63, wave = tid >> 6;
     own = sh.tabF[tid];
     uint32_t inc = own;
@@ -123,8 +124,8 @@ __device__ __forceinline__ uint32_t scan_f_part1(Smem<G>& sh, int tid, uint32_t&
     return inc;
 }
 
-template <class G>
-__device__ __forceinline__ void scan_f_part2(Smem<G>& sh, int tid, uint32_t inc, uint32_t own) {
+template <class G, class M>
+__device__ __forceinline__ void scan_f_part2(M& sh, int tid, uint32_t inc, uint32_t own) {
     const int wave = tid >> 6;
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += sh.wtotF[w];
@@ -574,11 +575,11 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         }
         STAMP(8);
         uint32_t fown;
-        const uint32_t finc = scan_f_part1(sh, tid, fown);
+        const uint32_t finc = scan_f_part1<G>(sh, tid, fown);
         STAMP(9);
         __syncthreads();  // B3
         STAMP(10);
-        scan_f_part2(sh, tid, finc, fown);
+        scan_f_part2<G>(sh, tid, finc, fown);
         __syncthreads();  // B4
         STAMP(11);
         const uint32_t k0 = sh.cur_k0;
@@ -732,6 +733,188 @@ __global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, Blo
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// device-side emit: k_offsets + k_emit
+// ---------------------------------------------------------------------------------------------
+// One workgroup: byte size of every block's payload ([flag] + the two chosen channel blocks), exclusive
+// prefix -> block_off[0..nb], and the container's block table entries (frames, bytes).
+__global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+                                                   const ChannelPlan* __restrict__ plans,
+                                                   unsigned long long* __restrict__ block_off,
+                                                   uint32_t* __restrict__ table) {
+    __shared__ unsigned long long s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nb = prm.num_blocks;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t b0 = (uint32_t)tid * per;
+    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
+    unsigned long long sum = 0;
+    for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
+        const ChannelPlan* p = plans + (size_t)b * kSlotsPerBlock;
+        uint32_t bytes;
+        if (prm.channels == 1) {
+            bytes = p[CH_L].payload_bytes;
+        } else {
+            const bool ms = bplans[b].choose_ms != 0;
+            bytes = (ms ? p[CH_M].payload_bytes + p[CH_S].payload_bytes : p[CH_L].payload_bytes + p[CH_R].payload_bytes) +
+                    (autost ? 1u : 0u);
+        }
+        table[2 * b] = bplans[b].frames;
+        table[2 * b + 1] = bytes;
+        sum += bytes;
+    }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = shfl_up_u64(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    unsigned long long run = base + inc - sum;
+    for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
+        block_off[b] = run;
+        run += table[2 * b + 1];
+    }
+    if (tid == 1023) block_off[nb] = base + inc;
+}
+
+// suffix-min scan of tabNX (first non-zero index per chunk) -> exclusive: min over later chunks
+template <class G>
+__device__ __forceinline__ int32_t scan_nx_part1(EmitMem<G>& sh, int tid, int32_t* wtot) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t v = sh.tabNX[tid];
+    int32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc = o < inc ? o : inc;
+    }
+    if (lane == 0) wtot[wave] = inc;
+    return inc;
+}
+
+template <class G>
+__device__ __forceinline__ void scan_nx_part2(EmitMem<G>& sh, int tid, int32_t inc, const int32_t* wtot, int32_t n) {
+    constexpr int NW = G::T / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t later = n;
+    for (int w = wave + 1; w < NW; ++w) later = wtot[w] < later ? wtot[w] : later;
+    int32_t next = __shfl_down(inc, 1, 64);
+    if (lane == 63) next = n;
+    sh.tabNX[tid] = next < later ? next : later;
+}
+
+template <class G>
+__global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
+                                               AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+                                               const ChannelPlan* __restrict__ plans,
+                                               const unsigned long long* __restrict__ block_off,
+                                               uint8_t* __restrict__ out, uint32_t* __restrict__ err_flag) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
+    __shared__ int32_t s_wx[16];
+    const int tid = threadIdx.x;
+    const uint32_t per = prm.channels == 2 ? 2u : 1u;
+    const uint32_t blk = blockIdx.x / per;
+    const int which = (int)(blockIdx.x % per);
+    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
+    const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
+    const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
+    const int kind = which == 0 ? first_kind : (ms ? CH_S : CH_R);
+    const ChannelPlan* plan = plans + (size_t)blk * kSlotsPerBlock + kind;
+    const uint32_t n = block_frames(prm, blk);
+    unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
+    if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
+    if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+
+    Thread<G> th;
+    thread_init(th, n, tid);
+    stage_samples(th, sh, slot_src(L, R, kind), (int64_t)blk * kMaxBlock);
+    if (tid == 0) {
+        emit_load_plan(sh, *plan);
+        if (!plan->valid) sh.err = 1;
+    }
+    __syncthreads();
+    phase_r(th, sh, (int)sh.cand);
+    emit_first_nonzero(th, sh);
+    ScanRegs<G> sr;
+    scan_pz_part1<G>(sh, tid, sr);
+    const int32_t nxinc = scan_nx_part1(sh, tid, s_wx);
+    __syncthreads();
+    scan_pz_part2<G>(sh, tid, sr);
+    scan_nx_part2(sh, tid, nxinc, s_wx, (int32_t)n);
+    __syncthreads();
+    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
+    if (adaptive0) {
+        if (narrow) {
+            phase_a<G, true>(th, sh);
+        } else {
+            phase_a<G, false>(th, sh);
+        }
+        uint32_t fown;
+        const uint32_t finc = scan_f_part1<G>(sh, tid, fown);
+        __syncthreads();
+        scan_f_part2<G>(sh, tid, finc, fown);
+        __syncthreads();
+    }
+    auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
+    // walk 1: Rice parameter per sample + token bits of the chunk
+    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw)
+                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw);
+    __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
+    sh.tabP[tid] = mybits;
+    {
+        // sum scan of the bit counts (tabP only)
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long inc = mybits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = shfl_up_u64(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) sh.wtotP[wave] = inc;
+        __syncthreads();
+        unsigned long long base = 0;
+        for (int w = 0; w < wave; ++w) base += sh.wtotP[w];
+        sh.tabP[tid] = base + inc - mybits;
+        if (tid == G::T - 1) sh.tabP[G::T] = base + inc;
+        __syncthreads();
+    }
+    const unsigned long long total_bits = sh.tabP[G::T] + sh.header_bits;
+    const unsigned long long nbytes = (total_bits + 7u) >> 3;
+    if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
+    if (nbytes != sh.payload_bytes || sh.err) return;  // uniform: never write outside the planned byte range
+    const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
+
+    // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
+    for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
+        for (int i = tid; i < kEmitTileWords; i += G::T) sh.xp.o.obits[i] = 0;
+        __syncthreads();
+        BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
+        if (bit0 == 0) emit_header(th, sh, &tile, orw);
+        const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
+        if (mypos < tile_end && mypos + mybits > bit0) {
+            if (narrow) {
+                emit_walk<G, true>(th, sh, &tile, mypos, orw);
+            } else {
+                emit_walk<G, false>(th, sh, &tile, mypos, orw);
+            }
+        }
+        __syncthreads();
+        const unsigned long long byte0 = bit0 >> 3;
+        const unsigned long long left = nbytes - byte0;
+        const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
+        uint8_t* dst = out + off + byte0;
+        for (uint32_t i = tid; i < count; i += G::T) dst[i] = (uint8_t)(sh.xp.o.obits[i >> 2] >> (24u - 8u * (i & 3u)));
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------
@@ -752,6 +935,25 @@ int debug_read_stamps(unsigned long long* out32) {
 #endif
 }
 size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
+
+hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
+                       const DeviceWorkspace& ws, uint8_t* d_payload, hipStream_t stream) {
+    static bool attr_done = false;
+    static hipError_t attr_err = hipSuccess;
+    if (!attr_done) {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emit<GFull>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitMem<GFull>));
+        attr_done = true;
+    }
+    if (attr_err != hipSuccess) return attr_err;
+    const uint32_t nb = prm.num_blocks;
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, stream, prm, ws.bplans, ws.plans, ws.block_off, ws.table);
+    hipLaunchKernelGGL(k_emit<GFull>, dim3(nb * (prm.channels == 2 ? 2u : 1u)), dim3(GFull::T),
+                       sizeof(EmitMem<GFull>), stream, d_left, d_right, prm, ws.bplans, ws.plans, ws.block_off,
+                       d_payload, ws.err_flag);
+    return hipGetLastError();
+}
 
 static hipError_t set_smem_attr() {
     static hipError_t cached = hipErrorUnknown;

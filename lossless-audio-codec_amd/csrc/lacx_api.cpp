@@ -38,8 +38,9 @@ struct lacx_encoder {
     bool device_ready = false;
     int device = 0;
     hipStream_t stream[kStreams] = {};
-    hipEvent_t ev[kMaxChunks][5] = {};
+    hipEvent_t ev[kMaxChunks][6] = {};  // [5]: after the device emit kernels
     hipEvent_t done[kMaxChunks] = {};
+    hipEvent_t copied[kMaxChunks] = {};
     DeviceWorkspace ws{};
     uint32_t ws_blocks = 0;
     int32_t* d_left = nullptr;
@@ -48,6 +49,17 @@ struct lacx_encoder {
     ChannelPlan* h_plans = nullptr;  // pinned
     BlockPlan* h_bplans = nullptr;   // pinned
     uint32_t h_blocks = 0;
+    // device emit
+    uint8_t* d_payload = nullptr;
+    uint64_t d_payload_cap = 0;
+    uint8_t* h_payload = nullptr;  // pinned
+    uint64_t h_payload_cap = 0;
+    uint32_t* h_table = nullptr;   // pinned, [blocks][2]
+    unsigned long long* h_totals = nullptr;  // pinned, per chunk payload bytes
+    uint32_t* h_err = nullptr;     // pinned, per chunk
+    uint32_t h_table_blocks = 0;
+    uint8_t* view_buf = nullptr;   // result of the host-emit fallback kept alive for the *_view API
+    uint32_t* view_table = nullptr;
     std::unique_ptr<EmitPool> pool;
     std::string err;
     lacx_timing timing{};
@@ -88,6 +100,9 @@ int ensure_device(lacx_encoder* e) {
     for (auto& row : e->ev)
         for (auto& ev : row) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
     for (auto& ev : e->done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * kMaxChunks, 0), "hipHostMalloc");
     e->device_ready = true;
     return LACX_OK;
 }
@@ -110,6 +125,9 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.lpcs) (void)hipFree(e->ws.lpcs);
     if (e->ws.sums) (void)hipFree(e->ws.sums);
     if (e->ws.badidx) (void)hipFree(e->ws.badidx);
+    if (e->ws.block_off) (void)hipFree(e->ws.block_off);
+    if (e->ws.table) (void)hipFree(e->ws.table);
+    if (e->ws.err_flag) (void)hipFree(e->ws.err_flag);
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -126,6 +144,10 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.lpcs, slots * sizeof(LpcSet)), "hipMalloc(lpcs)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.sums, (size_t)nblocks * 12 * sizeof(unsigned long long)), "hipMalloc(sums)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.badidx, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(badidx)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
+                "hipMalloc(block_off)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.err_flag, sizeof(uint32_t) * kMaxChunks), "hipMalloc(err)");
         e->ws_blocks = nblocks;
     }
     if (nblocks > e->h_blocks) {
@@ -198,6 +220,7 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
     w.lpcs += s;
     w.sums += (size_t)first_block * 12;
     w.badidx += (size_t)first_block * 2;
+    w.table += (size_t)first_block * 2;
     return w;
 }
 
@@ -406,6 +429,130 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
     return LACX_OK;
 }
 
+// Device-emit pipeline: per chunk the kernels also produce the bitstream (k_offsets + k_emit); the host only
+// copies each chunk's payload into one pinned buffer at the running offset.  Results stay in encoder-owned
+// pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
+// pinned buffer was too small (the caller then falls back to the host-emit pipeline, same bytes).
+int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                            hipStream_t user_stream, uint64_t* payload_size) {
+    const int channels = d_right ? 2 : 1;
+    const uint32_t nb = blocks_for(frames);
+    int rc = ensure_workspace(e, nb);
+    if (rc) return rc;
+    const std::vector<Chunk> chunks = plan_chunks(nb);
+    // device arena: worst case per chunk (12 bytes per sample, see payload_upper_bound)
+    const uint64_t dev_cap = payload_upper_bound(frames, channels, nb) + 64ull * chunks.size();
+    if (dev_cap > e->d_payload_cap) {
+        if (e->d_payload) (void)hipFree(e->d_payload);
+        e->d_payload = nullptr;
+        e->d_payload_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_payload, dev_cap), "hipMalloc(payload)");
+        e->d_payload_cap = dev_cap;
+    }
+    // pinned result buffer: 1.25 x the PCM size at its source bit depth covers every realistic stream
+    const uint64_t host_cap = frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
+    if (host_cap > e->h_payload_cap) {
+        if (e->h_payload) (void)hipHostFree(e->h_payload);
+        e->h_payload = nullptr;
+        e->h_payload_cap = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_payload, host_cap, 0), "hipHostMalloc(payload)");
+        e->h_payload_cap = host_cap;
+    }
+    if (nb > e->h_table_blocks) {
+        if (e->h_table) (void)hipHostFree(e->h_table);
+        e->h_table = nullptr;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_table, (size_t)nb * 2 * sizeof(uint32_t), 0), "hipHostMalloc(table)");
+        e->h_table_blocks = nb;
+    }
+    reset_device_timing(e);
+    e->timing.emit_ms = 0;
+    const auto t0 = clk::now();
+    hipStream_t st[kStreams];
+    for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
+    if (user_stream) st[0] = user_stream;
+    std::vector<uint64_t> dev_off(chunks.size());
+    uint64_t doff = 0;
+    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, st[0]), "memset");
+    HIP_TRY(e, hipStreamSynchronize(st[0]), "synchronize");
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const Chunk& ck = chunks[c];
+        hipStream_t s = st[c % kStreams];
+        const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
+        const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
+        const AnalyzeParams prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth);
+        DeviceWorkspace w = ws_at(e->ws, ck.first);
+        w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
+        w.err_flag = e->ws.err_flag + c;
+        dev_off[c] = doff;
+        doff += payload_upper_bound(f1 - f0, channels, ck.count) + 64u;
+        HIP_TRY(e, launch_analysis(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, s, e->ev[c]), "kernel launch");
+        HIP_TRY(e, launch_emit(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, e->d_payload + dev_off[c], s),
+                "emit launch");
+        HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
+        HIP_TRY(e, hipMemcpyAsync(e->h_bplans + ck.first, w.bplans, (size_t)ck.count * sizeof(BlockPlan),
+                                  hipMemcpyDeviceToHost, s), "D2H block plans");
+        HIP_TRY(e, hipMemcpyAsync(e->h_table + (size_t)ck.first * 2, w.table, (size_t)ck.count * 2 * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s), "D2H table");
+        HIP_TRY(e, hipMemcpyAsync(&e->h_totals[c], w.block_off + ck.count, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, s), "D2H total");
+        HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
+        HIP_TRY(e, hipEventRecord(e->done[c], s), "event record");
+    }
+    uint64_t off = 0;
+    int status = LACX_OK;
+    size_t copies = 0;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const hipError_t he = hipEventSynchronize(e->done[c]);
+        if (he != hipSuccess) {
+            status = hip_fail(e, he, "event synchronize");
+            break;
+        }
+        const Chunk& ck = chunks[c];
+        bool bad = false;
+        for (uint32_t b = ck.first; b < ck.first + ck.count; ++b) bad = bad || e->h_bplans[b].invalid;
+        if (bad) {
+            status = LACX_E_INVALID;
+            break;
+        }
+        if (e->h_err[c]) {
+            status = fail(e, LACX_E_RUNTIME, "device emit disagrees with the analysis plan (internal error)");
+            break;
+        }
+        const uint64_t total = e->h_totals[c];
+        if (off + total > e->h_payload_cap) {
+            status = -1;  // reservation too small: let the caller use the host-emit pipeline
+            break;
+        }
+        hipStream_t s = st[c % kStreams];
+        const hipError_t ce = hipMemcpyAsync(e->h_payload + off, e->d_payload + dev_off[c], total, hipMemcpyDeviceToHost, s);
+        if (ce != hipSuccess || hipEventRecord(e->copied[c], s) != hipSuccess) {
+            status = hip_fail(e, ce, "D2H payload");
+            break;
+        }
+        ++copies;
+        off += total;
+    }
+    for (size_t c = 0; c < copies; ++c) (void)hipEventSynchronize(e->copied[c]);
+    e->timing.d2h_ms = ms_since(t0);
+    if (status != LACX_OK) {
+        (void)hipDeviceSynchronize();
+        if (status == LACX_E_INVALID) {
+            const int rr = check_sample_range(e, nb);
+            return rr ? rr : fail(e, LACX_E_INVALID, "sample outside the configured PCM bit depth");
+        }
+        return status;
+    }
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        add_chunk_timing(e, (int)c);
+        float f = 0;
+        if (hipEventElapsedTime(&f, e->ev[c][4], e->ev[c][5]) == hipSuccess) e->timing.emit_ms += f;
+    }
+    e->timing.full_launches = (uint32_t)chunks.size();
+    e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
+    *payload_size = off;
+    return LACX_OK;
+}
+
 int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                         const int32_t*& h_left, const int32_t*& h_right, std::vector<int32_t>& tl,
                         std::vector<int32_t>& tr) {
@@ -477,6 +624,8 @@ int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out) {
 void lacx_encoder_destroy(lacx_encoder* e) {
     if (!e) return;
     e->pool.reset();
+    std::free(e->view_buf);
+    std::free(e->view_table);
     if (e->device_ready) {
         (void)hipSetDevice(e->device);
         free_workspace(e);
@@ -489,6 +638,13 @@ void lacx_encoder_destroy(lacx_encoder* e) {
                 if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : e->done)
             if (ev) (void)hipEventDestroy(ev);
+        for (auto& ev : e->copied)
+            if (ev) (void)hipEventDestroy(ev);
+        if (e->d_payload) (void)hipFree(e->d_payload);
+        if (e->h_payload) (void)hipHostFree(e->h_payload);
+        if (e->h_table) (void)hipHostFree(e->h_table);
+        if (e->h_totals) (void)hipHostFree(e->h_totals);
+        if (e->h_err) (void)hipHostFree(e->h_err);
         for (auto& s : e->stream)
             if (s) (void)hipStreamDestroy(s);
     }
@@ -581,11 +737,35 @@ int lacx_encode_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_
     e->timing.h2d_ms = h2d;
     int rc = prepare(e, d_left, frames);
     if (rc) return rc;
+    const uint32_t nb = blocks_for(frames);
+    const uint64_t head = 10 + 4 + 8ull * nb;
+    if (!(e->cfg.flags & LACX_FLAG_HOST_EMIT)) {
+        uint64_t pay = 0;
+        rc = encode_pipelined_device(e, d_left, d_right, frames, static_cast<hipStream_t>(stream), &pay);
+        if (rc == LACX_OK) {
+            uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + pay));
+            if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
+            write_frame_header(stream_params(e->cfg, d_right ? 2 : 1), buf);
+            put32(buf + 10, nb);
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (e->h_table[2 * b + 1] == 0) {
+                    std::free(buf);
+                    return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+                }
+                put32(buf + 14 + 8ull * b, e->h_table[2 * b]);
+                put32(buf + 18 + 8ull * b, e->h_table[2 * b + 1]);
+            }
+            std::memcpy(buf + head, e->h_payload, pay);
+            *out = buf;
+            *out_size = head + pay;
+            e->timing.total_ms = ms_since(t0);
+            return LACX_OK;
+        }
+        if (rc != -1) return rc;  // -1: pinned reservation too small -> host-emit pipeline below
+    }
     std::vector<int32_t> tl, tr;
     rc = fetch_pcm_if_needed(e, d_left, d_right, frames, h_left, h_right, tl, tr);
     if (rc) return rc;
-    const uint32_t nb = blocks_for(frames);
-    const uint64_t head = 10 + 4 + 8ull * nb;
     uint8_t* buf = nullptr;
     uint64_t pay = 0;
     std::vector<uint64_t> offsets;
@@ -619,15 +799,11 @@ int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint
     return rc;
 }
 
-int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,
-                             const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
-                             uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
-    if (!e || !payload || !payload_size || !table || !nblocks || !h_left) return LACX_E_INVALID;
-    const auto t0 = clk::now();
-    const double h2d = e->timing.h2d_ms;
-    e->timing = lacx_timing{};
-    e->timing.h2d_ms = h2d;
-    int rc = prepare(e, d_left, frames);
+static int shard_host_path(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, const int32_t* h_left,
+                           const int32_t* h_right, uint64_t frames, void* stream, uint8_t** payload,
+                           uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
+    std::vector<int32_t> tl, tr;
+    int rc = fetch_pcm_if_needed(e, d_left, d_right, frames, h_left, h_right, tl, tr);
     if (rc) return rc;
     const uint32_t nb = blocks_for(frames);
     uint8_t* buf = nullptr;
@@ -649,8 +825,73 @@ int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32
     *payload_size = pay;
     *table = tab;
     *nblocks = nb;
+    return LACX_OK;
+}
+
+int lacx_encode_shard_device_view(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,
+                                  const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                                  const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                                  uint32_t* nblocks) {
+    if (!e || !payload || !payload_size || !table || !nblocks) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    const double h2d = e->timing.h2d_ms;
+    e->timing = lacx_timing{};
+    e->timing.h2d_ms = h2d;
+    int rc = prepare(e, d_left, frames);
+    if (rc) return rc;
+    if (!(e->cfg.flags & LACX_FLAG_HOST_EMIT)) {
+        uint64_t pay = 0;
+        rc = encode_pipelined_device(e, d_left, d_right, frames, static_cast<hipStream_t>(stream), &pay);
+        if (rc == LACX_OK) {
+            *payload = e->h_payload;
+            *payload_size = pay;
+            *table = e->h_table;
+            *nblocks = blocks_for(frames);
+            e->timing.total_ms = ms_since(t0);
+            return LACX_OK;
+        }
+        if (rc != -1) return rc;
+    }
+    std::free(e->view_buf);
+    std::free(e->view_table);
+    e->view_buf = nullptr;
+    e->view_table = nullptr;
+    uint8_t* buf = nullptr;
+    uint32_t* tab = nullptr;
+    rc = shard_host_path(e, d_left, d_right, h_left, h_right, frames, stream, &buf, payload_size, &tab, nblocks);
+    if (rc) return rc;
+    e->view_buf = buf;
+    e->view_table = tab;
+    *payload = buf;
+    *table = tab;
     e->timing.total_ms = ms_since(t0);
     e->timing.emit_ms = e->timing.total_ms - e->timing.d2h_ms;
+    return LACX_OK;
+}
+
+int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,
+                             const int32_t* h_left, const int32_t* h_right, uint64_t frames, void* stream,
+                             uint8_t** payload, uint64_t* payload_size, uint32_t** table, uint32_t* nblocks) {
+    if (!e || !payload || !payload_size || !table || !nblocks) return LACX_E_INVALID;
+    const uint8_t* vp = nullptr;
+    const uint32_t* vt = nullptr;
+    uint64_t pay = 0;
+    uint32_t nb = 0;
+    const int rc = lacx_encode_shard_device_view(e, d_left, d_right, h_left, h_right, frames, stream, &vp, &pay, &vt, &nb);
+    if (rc) return rc;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(pay ? pay : 1));
+    uint32_t* tab = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * 2 * (nb ? nb : 1)));
+    if (!buf || !tab) {
+        std::free(buf);
+        std::free(tab);
+        return fail(e, LACX_E_RUNTIME, "out of memory");
+    }
+    std::memcpy(buf, vp, pay);
+    std::memcpy(tab, vt, sizeof(uint32_t) * 2 * nb);
+    *payload = buf;
+    *payload_size = pay;
+    *table = tab;
+    *nblocks = nb;
     return LACX_OK;
 }
 

@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("partitioning_enabled", C.c_uint8),
         ("device", C.c_int32),
         ("emit_threads", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
 
 
@@ -82,7 +83,7 @@ class Timing(C.Structure):
 EXPORTS = (
     "lacx_encoder_create", "lacx_encoder_destroy", "lacx_last_error", "lacx_free", "lacx_get_timing",
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
-    "lacx_encode_shard", "lacx_encode_shard_device", "lacx_assemble", "lacx_block_encode",
+    "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count",
 )
 
@@ -145,7 +146,7 @@ class Encoder:
                  debug_lpc: bool = False, debug_stereo_est: bool = False, debug_zr: bool = False,
                  device: int = -1):
         self.order = order  # stored and ignored, as in the reference (ref block/encoder.cpp:41)
-        self._cfg = Config(sample_rate & 0xFFFFFFFF, bit_depth & 0xFF, stereo_mode & 0xFF, 1, 1, device, 0)
+        self._cfg = Config(sample_rate & 0xFFFFFFFF, bit_depth & 0xFF, stereo_mode & 0xFF, 1, 1, device, 0, 0)
         self._raw_stereo_mode = stereo_mode
         self._h = None
 
@@ -163,6 +164,11 @@ class Encoder:
 
     def set_thread_count(self, max_threads: int):
         self._cfg.emit_threads = int(max_threads)
+        self._reset()
+
+    def set_host_emit(self, enabled: bool):
+        """True keeps the bit emit on the host (north_star layout); default is the device-side emit."""
+        self._cfg.flags = (self._cfg.flags | 1) if enabled else (self._cfg.flags & ~1)
         self._reset()
 
     # -- plumbing ------------------------------------------------------------------------------
@@ -284,6 +290,26 @@ class Encoder:
         if rc != OK:
             _raise(h, rc)
 
+    def encode_shard_device_view(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
+                                 stream: int = 0):
+        """Zero-copy shard encode: (PayloadView, table) backed by encoder-owned pinned memory."""
+        hl, hlp = _i32(h_left)
+        hrp = None
+        if h_right is not None:
+            hr, hrp = _i32(h_right)
+        pay = C.POINTER(C.c_uint8)()
+        psize = C.c_uint64()
+        tab = C.POINTER(C.c_uint32)()
+        nb = C.c_uint32()
+        h = self._handle()
+        rc = lib().lacx_encode_shard_device_view(h, C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr or 0), hlp, hrp,
+                                                 C.c_uint64(frames), C.c_void_p(stream), C.byref(pay),
+                                                 C.byref(psize), C.byref(tab), C.byref(nb))
+        if rc != OK:
+            _raise(h, rc)
+        table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))
+        return PayloadView(pay, psize.value), table
+
     def encode_shard_device(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
                             stream: int = 0, copy: bool = True):
         """Shard encode of device-resident PCM. With copy=False the payload comes back as a zero-copy
@@ -307,6 +333,20 @@ class Encoder:
         if not copy:
             return Payload(pay, psize.value), table
         return _take(pay, psize), table
+
+
+class PayloadView:
+    """Borrowed view of encoder-owned pinned memory (valid until the encoder's next call)."""
+
+    def __init__(self, ptr, size):
+        self._ptr = ptr
+        self.size = size
+
+    def __len__(self):
+        return self.size
+
+    def tobytes(self) -> bytes:
+        return C.string_at(self._ptr, self.size)
 
 
 class Payload:
@@ -337,7 +377,7 @@ class Payload:
 def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:
     """Header + block table + payload concat of (payload, table) shards given in stream order
     (ref src/codec/lac/encoder.cpp:243-250, 445-465)."""
-    cfg = Config(sample_rate, bit_depth, stereo_mode, 1, 1, -1, 0)
+    cfg = Config(sample_rate, bit_depth, stereo_mode, 1, 1, -1, 0, 0)
     n = len(shards)
     pays = (C.c_char_p * n)(*[s[0] for s in shards])
     sizes = (C.c_uint64 * n)(*[len(s[0]) for s in shards])

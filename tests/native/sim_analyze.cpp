@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "analyze_core.h"
+#include "emit_core.h"
 
 using namespace lacx;
 
@@ -162,9 +163,98 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
     return 0;
 }
 
+// Lock-step simulation of the device emit kernel: plan + samples -> exact channel-block bytes.
+template <class G>
+int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t* out, uint32_t cap) {
+    if (n == 0 || n > (uint32_t)G::MAXN) return -1;
+    EmitMem<G>* shp = new EmitMem<G>;
+    EmitMem<G>& sh = *shp;
+    std::memset(shp, 0, sizeof(EmitMem<G>));
+    std::vector<Thread<G>> th(G::T);
+    SlotSrc src{x, nullptr, CH_L};
+    for (int t = 0; t < G::T; ++t) {
+        thread_init(th[t], n, t);
+        stage_samples(th[t], sh, src, 0);
+    }
+    emit_load_plan(sh, *plan);
+    for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, (int)sh.cand);
+    {
+        uint64_t run = 0;
+        int32_t mx = -1;
+        for (int t = 0; t < G::T; ++t) {
+            const uint64_t v = sh.tabP[t];
+            const int32_t z = sh.tabNZ[t];
+            sh.tabP[t] = run;
+            sh.tabNZ[t] = mx;
+            run += v;
+            if (z > mx) mx = z;
+        }
+        sh.tabP[G::T] = run;
+    }
+    for (int t = 0; t < G::T; ++t) emit_first_nonzero(th[t], sh);
+    {
+        int32_t mn = (int32_t)n;
+        for (int t = G::T - 1; t >= 0; --t) {
+            const int32_t v = sh.tabNX[t];
+            sh.tabNX[t] = mn;
+            if (v < mn) mn = v;
+        }
+    }
+    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    if (sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3) {
+        for (int t = 0; t < G::T; ++t) {
+            if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
+        }
+        uint32_t run = 0;
+        for (int t = 0; t < G::T; ++t) {
+            const uint32_t v = sh.tabF[t];
+            sh.tabF[t] = run;
+            run += v;
+        }
+    }
+    auto orw = [](uint32_t* w, uint32_t v) { *w |= v; };
+    std::vector<uint64_t> bits(G::T), off(G::T);
+    for (int t = 0; t < G::T; ++t)
+        bits[t] = narrow ? emit_walk<G, true>(th[t], sh, nullptr, 0, orw) : emit_walk<G, false>(th[t], sh, nullptr, 0, orw);
+    uint64_t total = sh.header_bits;
+    for (int t = 0; t < G::T; ++t) {
+        off[t] = total;
+        total += bits[t];
+    }
+    const uint64_t bytes = (total + 7) / 8;
+    int rc = (int)bytes;
+    if (bytes != plan->payload_bytes) rc = -2;
+    if (bytes > cap) rc = -3;
+    if (rc >= 0) {
+        for (uint64_t bit0 = 0; bit0 < bytes * 8; bit0 += (uint64_t)kEmitTileWords * 32) {
+            for (int i = 0; i < kEmitTileWords; ++i) sh.xp.o.obits[i] = 0;
+            BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
+            for (int t = 0; t < G::T; ++t) {
+                emit_header(th[t], sh, &tile, orw);
+                if (narrow) emit_walk<G, true>(th[t], sh, &tile, off[t], orw); else emit_walk<G, false>(th[t], sh, &tile, off[t], orw);
+            }
+            const uint64_t byte0 = bit0 / 8;
+            for (uint64_t b = byte0; b < bytes && b < byte0 + (uint64_t)kEmitTileWords * 4; ++b) {
+                const uint64_t rel = b - byte0;
+                out[b] = (uint8_t)(sh.xp.o.obits[rel >> 2] >> (24 - 8 * (rel & 3)));
+            }
+        }
+    }
+    delete shp;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+// analysis + device-emit simulation of one channel block; returns bytes written or < 0
+int sim_block_encode(const int32_t* x, uint32_t n, int zero_run, int partitioning, int force_wide, uint8_t* out,
+                     uint32_t cap) {
+    ChannelPlan plan;
+    if (run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, &plan) != 0) return -1;
+    return run_emit_sim<Geo<16, 1024>>(x, n, &plan, out, cap);
+}
 
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
 // force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;

@@ -108,11 +108,13 @@ STREAMS = [
 ]
 
 
+@pytest.mark.parametrize("host_emit", [False, True], ids=["device_emit", "host_emit"])
 @pytest.mark.parametrize("case", STREAMS, ids=lambda c: "-".join(map(str, c)))
-def test_stream_bytes_match_oracle(gpu, oracle, case):
+def test_stream_bytes_match_oracle(gpu, oracle, case, host_emit):
     frames, ch, bd, sr, sm, kind, st = case
     left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=frames % 97 + 3, kind=kind, stereo=st)
     enc = gpu.lacx.Encoder(12, sm, sr, bd)
+    enc.set_host_emit(host_emit)
     got = enc.encode(left, right)
     want = oracle.encode(left, right, sr, bd, sm, threads=8)
     assert got == want
@@ -177,10 +179,12 @@ def test_golden_digests(gpu):
         g = ent["gen"]
         left, right = gpu.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"],
                                           seed=g["seed"], kind=g["kind"], stereo=g.get("stereo", "wide"))
-        enc = gpu.lacx.Encoder(12, ent["stereo_mode"], g["sample_rate"], g["bit_depth"])
-        got = enc.encode(left, right)
-        assert len(got) == ent["lac_bytes"], ent["name"]
-        assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], ent["name"]
+        for host_emit in (False, True):
+            enc = gpu.lacx.Encoder(12, ent["stereo_mode"], g["sample_rate"], g["bit_depth"])
+            enc.set_host_emit(host_emit)
+            got = enc.encode(left, right)
+            assert len(got) == ent["lac_bytes"], (ent["name"], host_emit)
+            assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], (ent["name"], host_emit)
 
 
 def test_cpp_mirror_classes_on_device(gpu):
