@@ -228,9 +228,12 @@ struct Chunk {
     uint32_t first, count;
 };
 
-std::vector<Chunk> plan_chunks(uint32_t nb) {
+// Host emit wants many chunks (emit of chunk i overlaps the analysis of chunk i+1); with the emit on the
+// device the only host work is a copy, and two chunks (payload copy of one under the kernels of the other)
+// measured best.
+std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false) {
     uint32_t nchunks = nb / kMinChunkBlocks;
-    nchunks = std::max(1u, std::min(nchunks, 8u));
+    nchunks = std::max(1u, std::min(nchunks, device_emit ? 2u : 8u));
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
         const unsigned long v = std::strtoul(env, nullptr, 0);
         if (v >= 1 && v <= (unsigned long)kMaxChunks) nchunks = std::min<uint32_t>((uint32_t)v, nb);
@@ -439,7 +442,7 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     const uint32_t nb = blocks_for(frames);
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
-    const std::vector<Chunk> chunks = plan_chunks(nb);
+    const std::vector<Chunk> chunks = plan_chunks(nb, true);
     // device arena: worst case per chunk (12 bytes per sample, see payload_upper_bound)
     const uint64_t dev_cap = payload_upper_bound(frames, channels, nb) + 64ull * chunks.size();
     if (dev_cap > e->d_payload_cap) {
