@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
+    ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
     args = ap.parse_args()
 
     import torch
@@ -74,8 +75,12 @@ def main():
     f1 = min(b1 * BLOCK, total_frames)
     frames = f1 - f0
     left, right = synth.synth_pcm(frames, 2, BIT_DEPTH, SAMPLE_RATE, seed=2026, kind=args.kind, start=f0)
-    d_left = torch.from_numpy(left).cuda()
-    d_right = torch.from_numpy(right).cuda()
+    interleaved = not (args.planar or args.host_emit or args.analysis_only)
+    if interleaved:  # the WAV data-chunk layout: interleaved little-endian int16, 2 bytes per sample in HBM
+        d_pcm = torch.from_numpy(synth.interleave(left, right, BIT_DEPTH).view(np.int16)).cuda()
+    else:
+        d_left = torch.from_numpy(left).cuda()
+        d_right = torch.from_numpy(right).cuda()
     torch.cuda.synchronize()
 
     enc = lacx.Encoder(12, STEREO_MODE, SAMPLE_RATE, BIT_DEPTH, device=local_rank)
@@ -91,8 +96,11 @@ def main():
         if args.analysis_only:
             enc.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
             return None
-        payload, table = enc.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames,
-                                                      stream)
+        if interleaved:
+            payload, table = enc.encode_shard_pcm_device_view(d_pcm.data_ptr(), lacx.PCM_INTERLEAVED_I16, 2, frames, stream)
+        else:
+            payload, table = enc.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames,
+                                                          stream)
         if world > 1:
             sizes = torch.from_numpy(table[:, 1].astype(np.int64)).cuda()
             mine = torch.tensor([int(sizes.sum().item()), table.shape[0]], dtype=torch.int64, device="cuda")
@@ -220,6 +228,7 @@ def main():
             "blocks_per_gpu": int(b1 - b0),
             "host_emit_threads": emit_threads,
             "emit": "host" if args.host_emit else "device",
+            "device_pcm_layout": "interleaved int16 (WAV data chunk)" if interleaved else "planar int32",
             "timed_region": ("device analysis (PCM resident in HBM) + plan D2H + host emit + shard table" if args.host_emit
                              else "device analysis + device bit emit (PCM resident in HBM) + payload/table D2H into pinned host memory")
                             + (" + RCCL all_gather of shard sizes" if world > 1 else ""),

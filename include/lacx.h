@@ -138,6 +138,24 @@ int lacx_encode_shard_device_view(lacx_encoder* enc, const int32_t* d_left, cons
                                   const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
                                   uint32_t* nblocks);
 
+/* Device-resident PCM in its source layout: the kernels read the WAV data chunk directly
+ * with coalesced loads, 2 or 3 bytes per sample instead of the 4 of the planar int32 API. */
+#define LACX_PCM_PLANAR_I32 0u      /* data0 = left, data1 = right (NULL for mono) */
+#define LACX_PCM_INTERLEAVED_I16 1u /* data0 = interleaved little-endian int16 frames, 4-byte aligned */
+#define LACX_PCM_INTERLEAVED_I24 2u /* data0 = interleaved packed 3-byte little-endian samples */
+typedef struct lacx_pcm {
+    const void* data0;
+    const void* data1;
+    uint32_t layout;
+    uint32_t channels; /* 1 or 2 */
+} lacx_pcm;
+
+/* Shard encode of device-resident PCM in any layout, device-side emit, zero-copy result (see
+ * lacx_encode_shard_device_view).  The configured bit depth must match an interleaved layout. */
+int lacx_encode_shard_pcm_device_view(lacx_encoder* enc, const lacx_pcm* d_pcm, uint64_t frames, void* stream,
+                                      const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                                      uint32_t* nblocks);
+
 /* Host-only: header + block table + payload concat of shards given in stream order. */
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
                   const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,

@@ -53,17 +53,44 @@ LACX_HD int sw(int j) {
 }
 
 // Where a slot's samples come from: a plain channel, or M/S derived on the fly
-// (ref src/codec/simd/neon.cpp:14-30: M = (L+R)>>1 arithmetic, S = L-R).
+// (ref src/codec/simd/neon.cpp:14-30: M = (L+R)>>1 arithmetic, S = L-R).  Three source layouts:
+//   PCM_PLANAR_I32       a = left, b = right, int32 per sample (the reference's API boundary)
+//   PCM_INTERLEAVED_I16  a = WAV data chunk: little-endian int16, frames interleaved (L R L R ...)
+//   PCM_INTERLEAVED_I24  a = WAV data chunk: packed 3-byte little-endian samples, interleaved
+enum : int { PCM_PLANAR_I32 = 0, PCM_INTERLEAVED_I16 = 1, PCM_INTERLEAVED_I24 = 2 };
+
 struct SlotSrc {
     const int32_t* a;
     const int32_t* b;
-    int kind;  // CH_L/CH_R: read a; CH_M / CH_S: combine a (left) and b (right)
+    int kind;  // CH_L / CH_R / CH_M / CH_S
+    int layout = PCM_PLANAR_I32;
+    int channels = 2;
 };
 
+LACX_HD int32_t sext24(uint32_t v) { return (int32_t)(v << 8) >> 8; }
+
 LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
-    const int32_t l = s.a[idx];
-    if (s.kind < CH_M) return l;
-    const int32_t r = s.b[idx];
+    int32_t l, r = 0;
+    if (s.layout == PCM_PLANAR_I32) {
+        if (s.kind == CH_L) return s.a[idx];
+        if (s.kind == CH_R) return s.b[idx];
+        l = s.a[idx];
+        r = s.b[idx];
+    } else if (s.layout == PCM_INTERLEAVED_I16) {
+        if (s.channels == 2) {
+            const uint32_t w = reinterpret_cast<const uint32_t*>(s.a)[idx];  // one 4-byte load per frame
+            l = (int32_t)(int16_t)(w & 0xFFFFu);
+            r = (int32_t)(int16_t)(w >> 16);
+        } else {
+            l = reinterpret_cast<const int16_t*>(s.a)[idx];
+        }
+    } else {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + idx * 3 * s.channels;
+        l = sext24((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
+        if (s.channels == 2) r = sext24((uint32_t)p[3] | ((uint32_t)p[4] << 8) | ((uint32_t)p[5] << 16));
+    }
+    if (s.kind == CH_L) return l;
+    if (s.kind == CH_R) return r;
     if (s.kind == CH_M) return (int32_t)((uint32_t)l + (uint32_t)r) >> 1;
     return (int32_t)((uint32_t)l - (uint32_t)r);
 }

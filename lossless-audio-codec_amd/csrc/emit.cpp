@@ -309,8 +309,8 @@ bool emit_one_block(const StreamParams& sp, const int32_t* left, const int32_t* 
     for (int c = 0; c < nch; ++c) {
         const ChannelPlan& pl = slots[kinds[c]];
         if (!pl.valid) return false;
-        const int32_t* a = (kinds[c] == CH_R) ? right + start : left + start;
-        const int32_t* bb = (kinds[c] >= CH_M) ? right + start : nullptr;
+        const int32_t* a = left + start;
+        const int32_t* bb = right ? right + start : nullptr;
         const size_t wrote = emit_channel(pl, a, bb, kinds[c], n, out, cap, scratch);
         if (wrote == (size_t)-1 || wrote != pl.payload_bytes) return false;
         out += wrote;

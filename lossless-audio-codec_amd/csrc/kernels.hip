@@ -222,18 +222,18 @@ __device__ __forceinline__ SlotGeom slot_geom(const AnalyzeParams& prm, uint32_t
     return g;
 }
 
-__device__ __forceinline__ SlotSrc slot_src(const int32_t* L, const int32_t* R, int ch) {
+__device__ __forceinline__ SlotSrc slot_src(const AnalyzeParams& prm, const int32_t* L, const int32_t* R, int ch) {
     SlotSrc s;
     s.kind = ch;
-    if (ch == CH_R) {
-        s.a = R;
-        s.b = nullptr;
-    } else {
-        s.a = L;
-        s.b = R;
-    }
+    s.a = L;  // planar: left; interleaved: the WAV data chunk
+    s.b = R;
+    s.layout = prm.layout;
+    s.channels = prm.channels;
     return s;
 }
+
+// first frame of block `blk` of the shard, as an index slot_fetch understands
+__device__ __forceinline__ int64_t block_start(uint32_t blk) { return (int64_t)blk * kMaxBlock; }
 
 // ---------------------------------------------------------------------------------------------
 // k_ingest: one workgroup per (block, channel in L,R,M,S)
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nb = block_frames(prm, blk);
     const int64_t bstart = (int64_t)blk * kMaxBlock;
-    const SlotSrc src = slot_src(L, R, ch);
+    const SlotSrc src = slot_src(prm, L, R, ch);
     const bool est = prm.channels == 2 && prm.stereo_mode == 2;
     const int32_t lo = prm.bit_depth == 16 ? -32768 : -0x800000;
     const int32_t hi = prm.bit_depth == 16 ? 32767 : 0x7FFFFF;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     const SlotGeom g = slot_geom(prm, blk, slot);
     const uint32_t n = g.n;
     const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
-    const SlotSrc src = slot_src(L, R, slot & 3);
+    const SlotSrc src = slot_src(prm, L, R, slot & 3);
 
 #ifdef LACX_STAMPS
     unsigned long long stamp_acc[24];
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
 
     Thread<G> th;
     thread_init(th, n, tid);
-    stage_samples(th, sh, slot_src(L, R, kind), (int64_t)blk * kMaxBlock);
+    stage_samples(th, sh, slot_src(prm, L, R, kind), (int64_t)blk * kMaxBlock);
     if (tid == 0) {
         emit_load_plan(sh, *plan);
         if (!plan->valid) sh.err = 1;

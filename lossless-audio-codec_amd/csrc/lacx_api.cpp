@@ -194,8 +194,10 @@ int validate_stream_args(lacx_encoder* e, const void* left, uint64_t frames) {
 
 uint32_t blocks_for(uint64_t frames) { return (uint32_t)((frames + kMaxBlock - 1) / kMaxBlock); }
 
-AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, int stereo_mode, int bit_depth) {
+AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, int stereo_mode, int bit_depth,
+                          int layout = 0) {
     AnalyzeParams prm{};
+    prm.layout = layout;
     prm.frames = frames;
     prm.num_blocks = blocks_for(frames);
     prm.first_block = 0;
@@ -437,8 +439,9 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
 // pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
 // pinned buffer was too small (the caller then falls back to the host-emit pipeline, same bytes).
 int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
-                            hipStream_t user_stream, uint64_t* payload_size) {
-    const int channels = d_right ? 2 : 1;
+                            hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0) {
+    const int channels = layout ? layout_channels : (d_right ? 2 : 1);
+    const uint64_t frame_bytes = layout == 1 ? 2ull * channels : (layout == 2 ? 3ull * channels : 4ull);
     const uint32_t nb = blocks_for(frames);
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
@@ -482,15 +485,18 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
         hipStream_t s = st[c % kStreams];
         const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
         const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
-        const AnalyzeParams prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth);
+        const AnalyzeParams prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
+        // chunk base pointers: planar int32 advances by frames, interleaved layouts by bytes
+        const int32_t* cl = layout ? reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(d_left) + f0 * frame_bytes)
+                                   : d_left + f0;
+        const int32_t* cr = (!layout && d_right) ? d_right + f0 : nullptr;
         DeviceWorkspace w = ws_at(e->ws, ck.first);
         w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
         w.err_flag = e->ws.err_flag + c;
         dev_off[c] = doff;
         doff += payload_upper_bound(f1 - f0, channels, ck.count) + 64u;
-        HIP_TRY(e, launch_analysis(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, s, e->ev[c]), "kernel launch");
-        HIP_TRY(e, launch_emit(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, e->d_payload + dev_off[c], s),
-                "emit launch");
+        HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c]), "kernel launch");
+        HIP_TRY(e, launch_emit(cl, cr, prm, w, e->d_payload + dev_off[c], s), "emit launch");
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
         HIP_TRY(e, hipMemcpyAsync(e->h_bplans + ck.first, w.bplans, (size_t)ck.count * sizeof(BlockPlan),
                                   hipMemcpyDeviceToHost, s), "D2H block plans");
@@ -869,6 +875,37 @@ int lacx_encode_shard_device_view(lacx_encoder* e, const int32_t* d_left, const 
     *table = tab;
     e->timing.total_ms = ms_since(t0);
     e->timing.emit_ms = e->timing.total_ms - e->timing.d2h_ms;
+    return LACX_OK;
+}
+
+int lacx_encode_shard_pcm_device_view(lacx_encoder* e, const lacx_pcm* pcm, uint64_t frames, void* stream,
+                                      const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                                      uint32_t* nblocks) {
+    if (!e || !pcm || !payload || !payload_size || !table || !nblocks) return LACX_E_INVALID;
+    if (pcm->layout == LACX_PCM_PLANAR_I32)
+        return lacx_encode_shard_device_view(e, static_cast<const int32_t*>(pcm->data0),
+                                             static_cast<const int32_t*>(pcm->data1), nullptr, nullptr, frames, stream,
+                                             payload, payload_size, table, nblocks);
+    const auto t0 = clk::now();
+    e->timing = lacx_timing{};
+    int rc = prepare(e, pcm->data0, frames);
+    if (rc) return rc;
+    if (pcm->channels != 1 && pcm->channels != 2) return fail(e, LACX_E_INVALID, "unsupported channel count");
+    const int want_depth = pcm->layout == LACX_PCM_INTERLEAVED_I16 ? 16 : (pcm->layout == LACX_PCM_INTERLEAVED_I24 ? 24 : 0);
+    if (want_depth == 0) return fail(e, LACX_E_INVALID, "unknown PCM layout");
+    if (e->cfg.bit_depth != want_depth) return fail(e, LACX_E_INVALID, "PCM layout does not match the configured bit depth");
+    if (e->cfg.flags & LACX_FLAG_HOST_EMIT)
+        return fail(e, LACX_E_INVALID, "interleaved device PCM needs the device-side emit");
+    uint64_t pay = 0;
+    rc = encode_pipelined_device(e, static_cast<const int32_t*>(pcm->data0), nullptr, frames,
+                                 static_cast<hipStream_t>(stream), &pay, (int)pcm->layout, (int)pcm->channels);
+    if (rc == -1) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
+    if (rc) return rc;
+    *payload = e->h_payload;
+    *payload_size = pay;
+    *table = e->h_table;
+    *nblocks = blocks_for(frames);
+    e->timing.total_ms = ms_since(t0);
     return LACX_OK;
 }
 

@@ -83,7 +83,7 @@ class Timing(C.Structure):
 EXPORTS = (
     "lacx_encoder_create", "lacx_encoder_destroy", "lacx_last_error", "lacx_free", "lacx_get_timing",
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
-    "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_assemble", "lacx_block_encode",
+    "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count",
 )
 
@@ -310,6 +310,21 @@ class Encoder:
         table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))
         return PayloadView(pay, psize.value), table
 
+    def encode_shard_pcm_device_view(self, data_ptr: int, layout: int, channels: int, frames: int, stream: int = 0):
+        """Zero-copy shard encode of device-resident PCM in its source layout (interleaved int16 / int24)."""
+        pcm = Pcm(data_ptr, None, layout, channels)
+        pay = C.POINTER(C.c_uint8)()
+        psize = C.c_uint64()
+        tab = C.POINTER(C.c_uint32)()
+        nb = C.c_uint32()
+        h = self._handle()
+        rc = lib().lacx_encode_shard_pcm_device_view(h, C.byref(pcm), C.c_uint64(frames), C.c_void_p(stream),
+                                                     C.byref(pay), C.byref(psize), C.byref(tab), C.byref(nb))
+        if rc != OK:
+            _raise(h, rc)
+        table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))
+        return PayloadView(pay, psize.value), table
+
     def encode_shard_device(self, d_left_ptr: int, d_right_ptr: int | None, h_left, h_right, frames: int,
                             stream: int = 0, copy: bool = True):
         """Shard encode of device-resident PCM. With copy=False the payload comes back as a zero-copy
@@ -333,6 +348,13 @@ class Encoder:
         if not copy:
             return Payload(pay, psize.value), table
         return _take(pay, psize), table
+
+
+class Pcm(C.Structure):
+    _fields_ = [("data0", C.c_void_p), ("data1", C.c_void_p), ("layout", C.c_uint32), ("channels", C.c_uint32)]
+
+
+PCM_PLANAR_I32, PCM_INTERLEAVED_I16, PCM_INTERLEAVED_I24 = 0, 1, 2
 
 
 class PayloadView:

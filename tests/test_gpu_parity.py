@@ -201,3 +201,22 @@ def test_forced_ms_still_validates_left_right(gpu):
     bad[16400] = 70000
     with pytest.raises(ValueError, match=r"left sample at index 16400 is outside"):
         gpu.lacx.Encoder(12, 1, 48000, 16).encode(bad, right)
+
+
+@pytest.mark.parametrize("case", [(16384 * 3 + 500, 2, 16, 48000, 2, "mixed"), (16384 * 2 + 77, 1, 16, 44100, 0, "music"),
+                                  (16384 * 2 + 4001, 2, 24, 96000, 2, "mixed"), (5000, 1, 24, 48000, 0, "noise"),
+                                  (16384 * 2, 2, 16, 48000, 1, "music")])
+def test_interleaved_device_ingest(gpu, oracle, case):
+    """WAV-layout PCM (interleaved int16 / packed int24) read directly by the kernels."""
+    import torch
+
+    frames, ch, bd, sr, sm, kind = case
+    left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=17, kind=kind)
+    inter = gpu.synth.interleave(left, right, bd)
+    d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+    enc = gpu.lacx.Encoder(12, sm, sr, bd, device=0)
+    layout = gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24
+    payload, table = enc.encode_shard_pcm_device_view(d.data_ptr(), layout, ch, frames,
+                                                      torch.cuda.current_stream().cuda_stream)
+    got = gpu.lacx.assemble(sr, bd, sm, ch, [(payload.tobytes(), table.copy())])
+    assert got == oracle.encode(left, right, sr, bd, sm, threads=8)
