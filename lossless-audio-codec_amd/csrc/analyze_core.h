@@ -236,12 +236,17 @@ LACX_HD void thread_init(Thread<G>& th, uint32_t n, int tid) {
 // ---------------------------------------------------------------------------------------------
 template <class G, class M>
 LACX_HD void stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
-    int32_t* col = &sh.xp.x[th.tid];
+    // all loads are issued before the first use (indices clamped into the slot, values masked after)
+    int32_t v[G::CH];
+    const int64_t last = start + (int64_t)th.n - 1;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
-        const int j = th.a + i;
-        col[i * G::T] = ((uint32_t)j < th.n) ? slot_fetch(src, start + j) : 0;
+        const int64_t idx = start + th.a + i;
+        v[i] = slot_fetch(src, idx < last ? idx : last);
     }
+    int32_t* col = &sh.xp.x[th.tid];
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) col[i * G::T] = (i < th.cnt) ? v[i] : 0;
 }
 
 // bit-sliced add of two W-bit counters held as W words (bit b of word l = bit l of the count of plane b)
