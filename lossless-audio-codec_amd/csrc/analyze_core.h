@@ -200,6 +200,7 @@ struct Smem {
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
+    uint32_t lbacc[2][2];          // block sums of Thread::lb_g / lb_aux (candidate pruning bound)
     uint64_t wtotP[16];  // per-wave totals used by the block scans
     int32_t wtotZ[16];
     uint32_t wtotF[16];
@@ -220,6 +221,8 @@ struct Thread {
     uint32_t cs[G::LV];  // bit-sliced per-plane counts of this chunk
     unsigned long long crice, cbin, czr;  // chunk partial costs
     uint32_t chasrun;
+    uint32_t lb_g;    // sum over the chunk of bit_width(u)+1 (per-sample floor of any Rice code)
+    uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16
 };
 
 template <class G>
@@ -349,12 +352,19 @@ LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
     }
     uint64_t s = 0;
     int32_t lastnz = -1;
+    uint32_t lbg = 0, lbaux = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         s += u[i];
         if (u[i] != 0) lastnz = th.a + i;
         sh.u[i * G::T + th.tid] = u[i];
+        if (i < th.cnt) {
+            lbg += (uint32_t)(32 - clz32(u[i])) + 1u;
+            lbaux += (u[i] == 0u ? 1u : 0u) + (u[i] == 4u ? 0x10000u : 0u);
+        }
     }
+    th.lb_g = lbg;
+    th.lb_aux = lbaux;
     sh.tabP[th.tid] = s;
     sh.tabNZ[th.tid] = lastnz;
     plane_counts<G>(u, th.cs);
@@ -489,6 +499,22 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     th.cbin = bin;
     th.czr = zr;
     th.chasrun = hasrun;
+}
+
+// Exact lower bound on min(rice, static, zero-run, bin) of a candidate, from three block sums:
+//   any Rice code of u costs >= bit_width(u) + 1 bits whatever k is (k = bit_width(u)-1 or bit_width(u) attain it);
+//   bin costs the same or more except u == 4 (3 bits against 4);
+//   zero-run costs >= 2 + that for every non-zero sample and >= 0 for zeros (they may sit in runs).
+// A candidate whose bound is >= the best exact cost so far cannot win (the reference replaces the best only
+// on a strictly smaller cost, ref block/encoder.cpp:352-359), so its adaptive cost passes can be skipped.
+LACX_HD uint64_t candidate_lower_bound(uint32_t g_sum, uint32_t aux_sum, uint32_t n, int zero_run) {
+    const uint32_t nzero = aux_sum & 0xFFFFu, n4 = aux_sum >> 16;
+    const uint64_t lb_rice = g_sum;
+    const uint64_t lb_bin = (uint64_t)g_sum - n4;
+    const uint64_t lb_zr = (uint64_t)g_sum - nzero + 2ull * (n - nzero);
+    uint64_t lb = lb_rice < lb_bin ? lb_rice : lb_bin;
+    if (zero_run && lb_zr < lb) lb = lb_zr;
+    return lb;
 }
 
 // Candidate scoring by thread 0 once the block reductions are in shared memory

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
     }
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
+    if (tid < 2) sh.lbacc[0][tid] = sh.lbacc[1][tid] = 0;
     if (tid == 0) sh.best_cand = -1;
     __syncthreads();
     STAMP(0);
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
             for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
             for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
+            sh.lbacc[parity ^ 1][0] = sh.lbacc[parity ^ 1][1] = 0;
+            pending = -1;
         }
         STAMP(1);
         phase_r(th, sh, cand);
@@ -557,9 +560,35 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         scan_pz_part1(sh, tid, sr);
         STAMP(3);
         if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
+        {
+            // block sums for the pruning bound
+            uint32_t g = th.lb_g, a = th.lb_aux;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                g += (uint32_t)__shfl_down((int)g, d, 64);
+                a += (uint32_t)__shfl_down((int)a, d, 64);
+            }
+            if ((tid & 63) == 0) {
+                atomicAdd(&sh.lbacc[parity][0], g);
+                atomicAdd(&sh.lbacc[parity][1], a);
+            }
+        }
         STAMP(4);
         __syncthreads();  // B1
         STAMP(5);
+        // Exact pruning: the previous candidates are scored (thread 0 did it before this barrier), so
+        // sh.best_bits is final for them; skip the adaptive passes of a candidate that cannot beat it.
+        if (!(prm.debug_skip & 128u) && sh.best_cand >= 0 &&
+            candidate_lower_bound(sh.lbacc[parity][0], sh.lbacc[parity][1], n, prm.zero_run) >= sh.best_bits) {
+            __syncthreads();  // every thread has read the bound before thread 0 clears the buffers
+            if (tid == 0) {
+                for (int b = 0; b < 32; ++b) pt[b] = pt256[b] = 0;
+                for (int b = 0; b < 4; ++b) acc[b] = 0;
+                sh.lbacc[parity][0] = sh.lbacc[parity][1] = 0;
+            }
+            __syncthreads();
+            continue;
+        }
         scan_pz_part2(sh, tid, sr);
         if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
         STAMP(6);
@@ -612,7 +641,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         pending_k0 = k0;
         parity ^= 1;
     }
-    if (tid == 0) score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
+    if (tid == 0 && pending >= 0) score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
     __syncthreads();
 
     STAMP(15);

@@ -78,6 +78,14 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, cand);
         scans_after_r(sh);
         plane_totals(sh, th);
+        {
+            uint32_t g = 0, a = 0;
+            for (int t = 0; t < G::T; ++t) {
+                g += th[t].lb_g;
+                a += th[t].lb_aux;
+            }
+            if (!(force_wide & 4) && sh.best_cand >= 0 && candidate_lower_bound(g, a, n, zero_run) >= sh.best_bits) continue;
+        }
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
         const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
         for (int t = 0; t < G::T; ++t) {
@@ -258,7 +266,7 @@ int sim_block_encode(const int32_t* x, uint32_t n, int zero_run, int partitionin
 
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
 // force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;
-// bit 1: use the per-order partition passes even where the fused pass applies
+// bit 1: use the per-order partition passes even where the fused pass applies; bit 2: no candidate pruning
 int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
                    ChannelPlan* out) {
     if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);
