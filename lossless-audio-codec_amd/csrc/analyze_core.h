@@ -517,6 +517,17 @@ LACX_HD uint64_t candidate_lower_bound(uint32_t g_sum, uint32_t aux_sum, uint32_
     return lb;
 }
 
+// Evaluation order of the 11 predictor candidates.  The reference walks them 0..10 and keeps the first
+// strictly smallest cost (ref block/encoder.cpp:352-359), i.e. the minimum of (cost, index); any order gives
+// the same winner when ties go to the lower index.  Likely winners go first so that the pruning bound bites
+// early: fixed order 2, then LPC 12 down to 4, then fixed 1, fixed 3, FIR, fixed 0, fixed 4.
+LACX_HD int candidate_at(int i) { return (int)((0x405316789A2ull >> (4 * i)) & 15ull); }
+
+// True when a candidate with lower bound `lb` cannot replace the best (cost, index) seen so far.
+LACX_HD bool candidate_pruned(uint64_t lb, int cand, uint64_t best_bits, int best_cand) {
+    return best_cand >= 0 && (lb > best_bits || (lb == best_bits && cand > best_cand));
+}
+
 // Candidate scoring by thread 0 once the block reductions are in shared memory
 // (ref block/encoder.cpp:337-359).  Returns nothing; updates sh.best_*.
 template <class G>
@@ -532,7 +543,7 @@ LACX_HD void score_candidate(Smem<G>& sh, int cand, uint32_t n, int zero_run, ui
     uint64_t a = rice < sbits ? rice : sbits;
     uint64_t b = zr < bin ? zr : bin;
     const uint64_t best = a < b ? a : b;
-    if (sh.best_cand < 0 || best < sh.best_bits) {
+    if (sh.best_cand < 0 || best < sh.best_bits || (best == sh.best_bits && cand < sh.best_cand)) {
         sh.best_cand = cand;
         sh.best_bits = best;
         sh.best_rice = rice;

@@ -538,7 +538,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     int pending = -1;        // candidate whose totals thread 0 still has to score
     uint32_t pending_k0 = 0;
     int parity = 0;
-    for (int cand = 0; cand <= 10; ++cand) {
+    for (int ci = 0; ci <= 10; ++ci) {
+        const int cand = candidate_at(ci);
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
         if (cand >= 6 && (prm.debug_skip & 16u)) continue;
         if (cand >= 1 && (prm.debug_skip & 64u)) continue;
@@ -578,8 +579,9 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         STAMP(5);
         // Exact pruning: the previous candidates are scored (thread 0 did it before this barrier), so
         // sh.best_bits is final for them; skip the adaptive passes of a candidate that cannot beat it.
-        if (!(prm.debug_skip & 128u) && sh.best_cand >= 0 &&
-            candidate_lower_bound(sh.lbacc[parity][0], sh.lbacc[parity][1], n, prm.zero_run) >= sh.best_bits) {
+        if (!(prm.debug_skip & 128u) &&
+            candidate_pruned(candidate_lower_bound(sh.lbacc[parity][0], sh.lbacc[parity][1], n, prm.zero_run), cand,
+                             sh.best_bits, sh.best_cand)) {
             __syncthreads();  // every thread has read the bound before thread 0 clears the buffers
             if (tid == 0) {
                 for (int b = 0; b < 32; ++b) pt[b] = pt256[b] = 0;

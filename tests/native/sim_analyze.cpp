@@ -73,7 +73,8 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
     const int max_valid_order = (n > 1) ? (int)((n - 1 < 32u) ? n - 1 : 32u) : 0;
     levinson_candidates(r, max_valid_order, sh.lpc.coef, sh.lpc.used);
     sh.best_cand = -1;
-    for (int cand = 0; cand <= 10; ++cand) {
+    for (int ci = 0; ci <= 10; ++ci) {
+        const int cand = candidate_at(ci);
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;
         for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, cand);
         scans_after_r(sh);
@@ -84,7 +85,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
                 g += th[t].lb_g;
                 a += th[t].lb_aux;
             }
-            if (!(force_wide & 4) && sh.best_cand >= 0 && candidate_lower_bound(g, a, n, zero_run) >= sh.best_bits) continue;
+            if (!(force_wide & 4) && candidate_pruned(candidate_lower_bound(g, a, n, zero_run), cand, sh.best_bits, sh.best_cand)) continue;
         }
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
         const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
