@@ -29,7 +29,9 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
 
 // Device-side emit of the analysed blocks of one chunk into d_payload (k_offsets + k_emit).
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                       const DeviceWorkspace& ws, uint8_t* d_payload, hipStream_t stream);
+                       const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
+                       const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
+                       hipEvent_t offsets_done, hipStream_t stream);
 
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.

@@ -773,7 +773,8 @@ __global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, Blo
 __global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
                                                    const ChannelPlan* __restrict__ plans,
                                                    unsigned long long* __restrict__ block_off,
-                                                   uint32_t* __restrict__ table) {
+                                                   uint32_t* __restrict__ table,
+                                                   const unsigned long long* __restrict__ base_ptr) {
     __shared__ unsigned long long s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = prm.num_blocks;
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const Block
     }
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    unsigned long long base = 0;
+    unsigned long long base = base_ptr ? *base_ptr : 0ull;  // bytes of the chunks before this one
     for (int w = 0; w < wave; ++w) base += s_w[w];
     unsigned long long run = base + inc - sum;
     for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
@@ -844,7 +845,8 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
                                                AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
                                                const ChannelPlan* __restrict__ plans,
                                                const unsigned long long* __restrict__ block_off,
-                                               uint8_t* __restrict__ out, uint32_t* __restrict__ err_flag) {
+                                               uint8_t* __restrict__ out, unsigned long long out_cap,
+                                               uint32_t* __restrict__ err_flag) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
     __shared__ int32_t s_wx[16];
@@ -860,6 +862,11 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     const uint32_t n = block_frames(prm, blk);
     unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
     if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
+    // the destination is sized from an estimate: if this block does not fit, report it and write nothing
+    if (block_off[blk + 1] > out_cap) {
+        if (tid == 0) atomicOr(err_flag, 2u);
+        return;
+    }
     if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
 
     Thread<G> th;
@@ -940,8 +947,38 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
         const unsigned long long byte0 = bit0 >> 3;
         const unsigned long long left = nbytes - byte0;
         const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
+        // Copy-out in 16-byte stores on 16-byte boundaries of the destination (which may be pinned host
+        // memory behind PCIe: whole, aligned segments matter there); the unaligned head and tail go bytewise.
         uint8_t* dst = out + off + byte0;
-        for (uint32_t i = tid; i < count; i += G::T) dst[i] = (uint8_t)(sh.xp.o.obits[i >> 2] >> (24u - 8u * (i & 3u)));
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const uint32_t head = mis ? (16u - mis < count ? 16u - mis : count) : 0u;
+        const uint32_t nvec = (count - head) >> 4;
+        const uint32_t* tw = sh.xp.o.obits;
+        auto tile_byte = [&](uint32_t i) { return (uint8_t)(tw[i >> 2] >> (24u - 8u * (i & 3u))); };
+        if ((uint32_t)tid < head) dst[tid] = tile_byte((uint32_t)tid);
+        {
+            const uint32_t r = head & 3u, j0 = head >> 2;
+            uint4* vdst = reinterpret_cast<uint4*>(dst + head);
+            for (uint32_t v = tid; v < nvec; v += G::T) {
+                const uint32_t j = j0 + 4u * v;
+                uint32_t w[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const uint32_t jj = j + q < (uint32_t)kEmitTileWords ? j + q : (uint32_t)kEmitTileWords - 1u;
+                    w[q] = __builtin_bswap32(tw[jj]);  // bytes of the stream in memory order
+                }
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbyte(w[1], w[0], r);
+                o.y = __builtin_amdgcn_alignbyte(w[2], w[1], r);
+                o.z = __builtin_amdgcn_alignbyte(w[3], w[2], r);
+                o.w = __builtin_amdgcn_alignbyte(w[4], w[3], r);
+                vdst[v] = o;
+            }
+        }
+        {
+            const uint32_t t0 = head + (nvec << 4);
+            if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
+        }
         __syncthreads();
     }
 }
@@ -968,7 +1005,9 @@ int debug_read_stamps(unsigned long long* out32) {
 size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
 
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                       const DeviceWorkspace& ws, uint8_t* d_payload, hipStream_t stream) {
+                       const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
+                       const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
+                       hipEvent_t offsets_done, hipStream_t stream) {
     static bool attr_done = false;
     static hipError_t attr_err = hipSuccess;
     if (!attr_done) {
@@ -979,10 +1018,19 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
     if (attr_err != hipSuccess) return attr_err;
     const uint32_t nb = prm.num_blocks;
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, stream, prm, ws.bplans, ws.plans, ws.block_off, ws.table);
+    if (wait_before_offsets) {
+        const hipError_t we = hipStreamWaitEvent(stream, wait_before_offsets, 0);
+        if (we != hipSuccess) return we;
+    }
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, stream, prm, ws.bplans, ws.plans, ws.block_off, ws.table,
+                       base_ptr);
+    if (offsets_done) {
+        const hipError_t re = hipEventRecord(offsets_done, stream);
+        if (re != hipSuccess) return re;
+    }
     hipLaunchKernelGGL(k_emit<GFull>, dim3(nb * (prm.channels == 2 ? 2u : 1u)), dim3(GFull::T),
                        sizeof(EmitMem<GFull>), stream, d_left, d_right, prm, ws.bplans, ws.plans, ws.block_off,
-                       d_payload, ws.err_flag);
+                       out, out_cap, ws.err_flag);
     return hipGetLastError();
 }
 

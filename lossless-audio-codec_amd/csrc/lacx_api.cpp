@@ -240,8 +240,35 @@ std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false) {
         const unsigned long v = std::strtoul(env, nullptr, 0);
         if (v >= 1 && v <= (unsigned long)kMaxChunks) nchunks = std::min<uint32_t>((uint32_t)v, nb);
     }
-    const uint32_t per = (nb + nchunks - 1) / nchunks;
     std::vector<Chunk> out;
+    if (const char* env = std::getenv("LACX_PIPE_SPLIT")) {  // tuning knob: relative chunk sizes, e.g. "5,3,1"
+        std::vector<double> w;
+        double sum = 0;
+        for (const char* p = env; *p && w.size() < (size_t)kMaxChunks;) {
+            char* end = nullptr;
+            const double v = std::strtod(p, &end);
+            if (end == p) break;
+            if (v > 0) {
+                w.push_back(v);
+                sum += v;
+            }
+            p = (*end == ',') ? end + 1 : end;
+        }
+        if (!w.empty() && nb >= w.size()) {
+            uint32_t f = 0;
+            double acc = 0;
+            for (size_t i = 0; i < w.size(); ++i) {
+                acc += w[i];
+                uint32_t end = i + 1 == w.size() ? nb : (uint32_t)(nb * (acc / sum));
+                end = std::max(end, f + 1);
+                end = std::min(end, nb - (uint32_t)(w.size() - 1 - i));
+                out.push_back({f, end - f});
+                f = end;
+            }
+            return out;
+        }
+    }
+    const uint32_t per = (nb + nchunks - 1) / nchunks;
     for (uint32_t f = 0; f < nb; f += per) out.push_back({f, std::min(per, nb - f)});
     return out;
 }
@@ -434,9 +461,9 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
     return LACX_OK;
 }
 
-// Device-emit pipeline: per chunk the kernels also produce the bitstream (k_offsets + k_emit); the host only
-// copies each chunk's payload into one pinned buffer at the running offset.  Results stay in encoder-owned
-// pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
+// Device-emit pipeline: per chunk the kernels also produce the bitstream (k_offsets + k_emit), written by the
+// kernel straight into one pinned host buffer at global byte offsets (chunk c starts where chunk c-1 ends).
+// Results stay in encoder-owned pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
 // pinned buffer was too small (the caller then falls back to the host-emit pipeline, same bytes).
 int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                             hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0) {
@@ -446,14 +473,22 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
     const std::vector<Chunk> chunks = plan_chunks(nb, true);
-    // device arena: worst case per chunk (12 bytes per sample, see payload_upper_bound)
-    const uint64_t dev_cap = payload_upper_bound(frames, channels, nb) + 64ull * chunks.size();
-    if (dev_cap > e->d_payload_cap) {
-        if (e->d_payload) (void)hipFree(e->d_payload);
-        e->d_payload = nullptr;
-        e->d_payload_cap = 0;
-        HIP_TRY(e, hipMalloc((void**)&e->d_payload, dev_cap), "hipMalloc(payload)");
-        e->d_payload_cap = dev_cap;
+    // Destination of k_emit: by default the pinned host buffer itself (the kernel's 16-byte stores cross PCIe
+    // while later blocks are still being analysed, so no separate D2H pass is left at the end); with
+    // LACX_EMIT_STAGED=1 a device arena sized for the worst case (12 bytes per sample), copied afterwards.
+    static const bool staged = [] {
+        const char* v = std::getenv("LACX_EMIT_STAGED");
+        return v && *v && *v != '0';
+    }();
+    if (staged) {
+        const uint64_t dev_cap = payload_upper_bound(frames, channels, nb) + 64ull;
+        if (dev_cap > e->d_payload_cap) {
+            if (e->d_payload) (void)hipFree(e->d_payload);
+            e->d_payload = nullptr;
+            e->d_payload_cap = 0;
+            HIP_TRY(e, hipMalloc((void**)&e->d_payload, dev_cap), "hipMalloc(payload)");
+            e->d_payload_cap = dev_cap;
+        }
     }
     // pinned result buffer: 1.25 x the PCM size at its source bit depth covers every realistic stream
     const uint64_t host_cap = frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
@@ -476,8 +511,13 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     hipStream_t st[kStreams];
     for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
     if (user_stream) st[0] = user_stream;
-    std::vector<uint64_t> dev_off(chunks.size());
-    uint64_t doff = 0;
+    uint8_t* emit_dst = e->d_payload;
+    uint64_t emit_cap = e->d_payload_cap;
+    if (!staged) {
+        HIP_TRY(e, hipHostGetDevicePointer((void**)&emit_dst, e->h_payload, 0), "hipHostGetDevicePointer");
+        emit_cap = e->h_payload_cap;
+    }
+    const unsigned long long* prev_end = nullptr;  // device address of the byte total of the chunks so far
     HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, st[0]), "memset");
     HIP_TRY(e, hipStreamSynchronize(st[0]), "synchronize");
     for (size_t c = 0; c < chunks.size(); ++c) {
@@ -493,10 +533,11 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
         DeviceWorkspace w = ws_at(e->ws, ck.first);
         w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
         w.err_flag = e->ws.err_flag + c;
-        dev_off[c] = doff;
-        doff += payload_upper_bound(f1 - f0, channels, ck.count) + 64u;
         HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c]), "kernel launch");
-        HIP_TRY(e, launch_emit(cl, cr, prm, w, e->d_payload + dev_off[c], s), "emit launch");
+        // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
+        HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
+                               e->copied[c], s), "emit launch");
+        prev_end = w.block_off + ck.count;
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
         HIP_TRY(e, hipMemcpyAsync(e->h_bplans + ck.first, w.bplans, (size_t)ck.count * sizeof(BlockPlan),
                                   hipMemcpyDeviceToHost, s), "D2H block plans");
@@ -523,25 +564,27 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
             status = LACX_E_INVALID;
             break;
         }
-        if (e->h_err[c]) {
+        if (e->h_err[c] & 1u) {
             status = fail(e, LACX_E_RUNTIME, "device emit disagrees with the analysis plan (internal error)");
             break;
         }
-        const uint64_t total = e->h_totals[c];
-        if (off + total > e->h_payload_cap) {
+        const uint64_t end = e->h_totals[c];  // cumulative
+        if ((e->h_err[c] & 2u) || end > e->h_payload_cap) {
             status = -1;  // reservation too small: let the caller use the host-emit pipeline
             break;
         }
-        hipStream_t s = st[c % kStreams];
-        const hipError_t ce = hipMemcpyAsync(e->h_payload + off, e->d_payload + dev_off[c], total, hipMemcpyDeviceToHost, s);
-        if (ce != hipSuccess || hipEventRecord(e->copied[c], s) != hipSuccess) {
-            status = hip_fail(e, ce, "D2H payload");
-            break;
+        if (staged) {
+            hipStream_t s = st[c % kStreams];
+            const hipError_t ce = hipMemcpyAsync(e->h_payload + off, e->d_payload + off, end - off, hipMemcpyDeviceToHost, s);
+            if (ce != hipSuccess || hipEventRecord(e->done[c], s) != hipSuccess) {
+                status = hip_fail(e, ce, "D2H payload");
+                break;
+            }
+            ++copies;
         }
-        ++copies;
-        off += total;
+        off = end;
     }
-    for (size_t c = 0; c < copies; ++c) (void)hipEventSynchronize(e->copied[c]);
+    for (size_t c = 0; c < copies; ++c) (void)hipEventSynchronize(e->done[c]);
     e->timing.d2h_ms = ms_since(t0);
     if (status != LACX_OK) {
         (void)hipDeviceSynchronize();
