@@ -200,7 +200,7 @@ struct Smem {
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
-    uint32_t lbacc[2][2];          // block sums of Thread::lb_g / lb_aux (candidate pruning bound)
+    uint32_t lbacc[11][2];         // per candidate: block sums of Thread::lb_g / lb_aux (pruning bound)
     uint64_t wtotP[16];  // per-wave totals used by the block scans
     int32_t wtotZ[16];
     uint32_t wtotF[16];

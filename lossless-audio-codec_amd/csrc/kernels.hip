@@ -530,7 +530,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
     }
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
-    if (tid < 2) sh.lbacc[0][tid] = sh.lbacc[1][tid] = 0;
+    if (tid < 22) (&sh.lbacc[0][0])[tid] = 0;
     if (tid == 0) sh.best_cand = -1;
     __syncthreads();
     STAMP(0);
@@ -551,7 +551,6 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
             for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
             for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
-            sh.lbacc[parity ^ 1][0] = sh.lbacc[parity ^ 1][1] = 0;
             pending = -1;
         }
         STAMP(1);
@@ -560,7 +559,6 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
         STAMP(3);
-        if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
         {
             // block sums for the pruning bound
             uint32_t g = th.lb_g, a = th.lb_aux;
@@ -570,32 +568,26 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
                 a += (uint32_t)__shfl_down((int)a, d, 64);
             }
             if ((tid & 63) == 0) {
-                atomicAdd(&sh.lbacc[parity][0], g);
-                atomicAdd(&sh.lbacc[parity][1], a);
+                atomicAdd(&sh.lbacc[cand][0], g);
+                atomicAdd(&sh.lbacc[cand][1], a);
             }
         }
         STAMP(4);
         __syncthreads();  // B1
         STAMP(5);
         // Exact pruning: the previous candidates are scored (thread 0 did it before this barrier), so
-        // sh.best_bits is final for them; skip the adaptive passes of a candidate that cannot beat it.
+        // sh.best_bits is final for them; a candidate that cannot beat it stops here, before the plane
+        // counts and the adaptive passes (its reduction buffers are untouched, so nothing needs clearing).
         if (!(prm.debug_skip & 128u) &&
-            candidate_pruned(candidate_lower_bound(sh.lbacc[parity][0], sh.lbacc[parity][1], n, prm.zero_run), cand,
-                             sh.best_bits, sh.best_cand)) {
-            __syncthreads();  // every thread has read the bound before thread 0 clears the buffers
-            if (tid == 0) {
-                for (int b = 0; b < 32; ++b) pt[b] = pt256[b] = 0;
-                for (int b = 0; b < 4; ++b) acc[b] = 0;
-                sh.lbacc[parity][0] = sh.lbacc[parity][1] = 0;
-            }
-            __syncthreads();
+            candidate_pruned(candidate_lower_bound(sh.lbacc[cand][0], sh.lbacc[cand][1], n, prm.zero_run), cand,
+                             sh.best_bits, sh.best_cand))
             continue;
-        }
         scan_pz_part2(sh, tid, sr);
-        if (tid == 0) sh.cur_k0 = initial_k_from_planes(pt256, n);
+        if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
         STAMP(6);
         __syncthreads();  // B2
         STAMP(7);
+        if (tid == (G::T > 64 ? 64 : 0)) sh.cur_k0 = initial_k_from_planes(pt256, n);  // read after B4
         const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
         if (prm.debug_skip & 2u) {
             sh.tabF[tid] = 0;
