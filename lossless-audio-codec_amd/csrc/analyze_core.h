@@ -68,6 +68,7 @@ struct SlotSrc {
 };
 
 LACX_HD int32_t sext24(uint32_t v) { return (int32_t)(v << 8) >> 8; }
+LACX_HD int32_t slot_combine(int kind, int32_t l, int32_t r);
 
 LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
     int32_t l, r = 0;
@@ -89,10 +90,7 @@ LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
         l = sext24((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
         if (s.channels == 2) r = sext24((uint32_t)p[3] | ((uint32_t)p[4] << 8) | ((uint32_t)p[5] << 16));
     }
-    if (s.kind == CH_L) return l;
-    if (s.kind == CH_R) return r;
-    if (s.kind == CH_M) return (int32_t)((uint32_t)l + (uint32_t)r) >> 1;
-    return (int32_t)((uint32_t)l - (uint32_t)r);
+    return slot_combine(s.kind, l, r);
 }
 
 LACX_HD uint32_t zigzag32(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
@@ -237,15 +235,117 @@ LACX_HD void thread_init(Thread<G>& th, uint32_t n, int tid) {
 // ---------------------------------------------------------------------------------------------
 // sample staging: x[sw(j)] = sample j (0 beyond n)
 // ---------------------------------------------------------------------------------------------
+LACX_HD int32_t slot_combine(int kind, int32_t l, int32_t r) {
+    if (kind == CH_L) return l;
+    if (kind == CH_R) return r;
+    if (kind == CH_M) return (int32_t)((uint32_t)l + (uint32_t)r) >> 1;
+    return (int32_t)((uint32_t)l - (uint32_t)r);
+}
+
+struct alignas(16) Vec16 {
+    uint32_t w[4];
+};
+
+template <int NV>
+LACX_HD void load_vec16(const void* p, uint32_t* w /* 4*NV */) {
+    const Vec16* q = static_cast<const Vec16*>(p);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const Vec16 t = q[k];
+        w[4 * k] = t.w[0];
+        w[4 * k + 1] = t.w[1];
+        w[4 * k + 2] = t.w[2];
+        w[4 * k + 3] = t.w[3];
+    }
+}
+
+// three bytes starting at byte `sh` (0..3) of the little-endian pair (lo, hi)
+LACX_HD uint32_t bytes3(uint32_t lo, uint32_t hi, int sh) {
+    const uint32_t x = sh == 0 ? lo : sh == 1 ? (lo >> 8) : sh == 2 ? ((lo >> 16) | (hi << 16)) : ((lo >> 24) | (hi << 8));
+    return x & 0xFFFFFFu;
+}
+
+LACX_HD bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// The CH consecutive frames of one thread are one contiguous 16-byte-aligned span in every supported layout
+// when the caller's buffer is 16-byte aligned: fetch them with 16-byte loads (a wave then touches each
+// cache line once instead of CH times).  Returns false when the span is not aligned or not a multiple of 16
+// bytes; the caller then takes the per-sample path.  Values are identical either way.
+template <int CH>
+LACX_HD bool stage_span(const SlotSrc& s, int64_t first, int32_t* v) {
+    if (s.layout == PCM_PLANAR_I32) {
+        if (CH % 4 != 0) return false;
+        const bool needa = s.kind != CH_R, needb = s.kind != CH_L;
+        if ((needa && !aligned16(s.a + first)) || (needb && !aligned16(s.b + first))) return false;
+        uint32_t la[CH] = {}, lb[CH] = {};
+        if (needa) load_vec16<CH / 4>(s.a + first, la);
+        if (needb) load_vec16<CH / 4>(s.b + first, lb);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = slot_combine(s.kind, (int32_t)la[i], (int32_t)lb[i]);
+        return true;
+    }
+    if (s.layout == PCM_INTERLEAVED_I16) {
+        if (s.channels == 2) {
+            if (CH % 4 != 0) return false;
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 4;
+            if (!aligned16(p)) return false;
+            uint32_t w[CH];
+            load_vec16<CH / 4>(p, w);
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                v[i] = slot_combine(s.kind, (int32_t)(int16_t)(w[i] & 0xFFFFu), (int32_t)(int16_t)(w[i] >> 16));
+            return true;
+        }
+        if (CH % 8 != 0) return false;
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 2;
+        if (!aligned16(p)) return false;
+        uint32_t w[CH / 2 > 0 ? CH / 2 : 1];
+        load_vec16<CH / 8>(p, w);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = (int32_t)(int16_t)((w[i / 2] >> (16 * (i & 1))) & 0xFFFFu);
+        return true;
+    }
+    // packed 24-bit little-endian
+    if (CH % 16 != 0) return false;
+    if (s.channels == 2) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 6;
+        if (!aligned16(p)) return false;
+        constexpr int ND = CH * 6 / 4;
+        uint32_t w[ND > 0 ? ND : 1];
+        load_vec16<ND / 4>(p, w);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int ol = i * 6, orr = i * 6 + 3;
+            v[i] = slot_combine(s.kind, sext24(bytes3(w[ol / 4], w[(ol / 4 + 1 < ND) ? ol / 4 + 1 : ol / 4], ol & 3)),
+                                sext24(bytes3(w[orr / 4], w[(orr / 4 + 1 < ND) ? orr / 4 + 1 : orr / 4], orr & 3)));
+        }
+        return true;
+    }
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 3;
+    if (!aligned16(p)) return false;
+    constexpr int ND = CH * 3 / 4;
+    uint32_t w[ND > 0 ? ND : 1];
+    load_vec16<ND / 4>(p, w);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int o = i * 3;
+        v[i] = sext24(bytes3(w[o / 4], w[(o / 4 + 1 < ND) ? o / 4 + 1 : o / 4], o & 3));
+    }
+    return true;
+}
+
 template <class G, class M>
 LACX_HD void stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
-    // all loads are issued before the first use (indices clamped into the slot, values masked after)
     int32_t v[G::CH];
-    const int64_t last = start + (int64_t)th.n - 1;
+    if (!(th.cnt == G::CH && stage_span<G::CH>(src, start + th.a, v))) {
+        // per-sample path: all loads are issued before the first use (indices clamped into the slot,
+        // values masked after)
+        const int64_t last = start + (int64_t)th.n - 1;
 #pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        const int64_t idx = start + th.a + i;
-        v[i] = slot_fetch(src, idx < last ? idx : last);
+        for (int i = 0; i < G::CH; ++i) {
+            const int64_t idx = start + th.a + i;
+            v[i] = slot_fetch(src, idx < last ? idx : last);
+        }
     }
     int32_t* col = &sh.xp.x[th.tid];
 #pragma unroll

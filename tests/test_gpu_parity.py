@@ -220,3 +220,32 @@ def test_interleaved_device_ingest(gpu, oracle, case):
                                                       torch.cuda.current_stream().cuda_stream)
     got = gpu.lacx.assemble(sr, bd, sm, ch, [(payload.tobytes(), table.copy())])
     assert got == oracle.encode(left, right, sr, bd, sm, threads=8)
+
+
+@pytest.mark.parametrize("bd", [16, 24])
+def test_unaligned_device_pointers(gpu, oracle, bd):
+    """Device buffers that are not 16-byte aligned take the per-sample staging path: same bytes."""
+    import torch
+
+    frames, ch, sr, sm = 16384 * 2 + 123, 2, 48000, 2
+    left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=23, kind="mixed")
+    want = oracle.encode(left, right, sr, bd, sm, threads=8)
+    enc = gpu.lacx.Encoder(12, sm, sr, bd, device=0)
+    # interleaved source shifted by one frame inside a larger allocation
+    inter = gpu.synth.interleave(left, right, bd)
+    flat = inter.view(np.int16).reshape(-1) if bd == 16 else inter.reshape(-1)
+    frame_elems = flat.size // frames
+    big = torch.zeros(flat.size + frame_elems, dtype=torch.int16 if bd == 16 else torch.uint8, device="cuda")
+    big[frame_elems:] = torch.from_numpy(flat.copy()).cuda()
+    layout = gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24
+    ptr = big.data_ptr() + frame_elems * big.element_size()
+    assert ptr % 16 != 0
+    payload, table = enc.encode_shard_pcm_device_view(ptr, layout, ch, frames, torch.cuda.current_stream().cuda_stream)
+    assert gpu.lacx.assemble(sr, bd, sm, ch, [(payload.tobytes(), table.copy())]) == want
+    # planar int32 shifted by one sample
+    dl = torch.zeros(frames + 1, dtype=torch.int32, device="cuda")
+    dr = torch.zeros(frames + 1, dtype=torch.int32, device="cuda")
+    dl[1:] = torch.from_numpy(left).cuda()
+    dr[1:] = torch.from_numpy(right).cuda()
+    torch.cuda.synchronize()
+    assert enc.encode_device(dl.data_ptr() + 4, dr.data_ptr() + 4, left, right, frames) == want
