@@ -95,6 +95,10 @@ LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
 
 LACX_HD uint32_t zigzag32(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
 
+LACX_HD int ctz32(uint32_t v) {  // v != 0
+    return __builtin_ctz(v);
+}
+
 LACX_HD int clz32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __clz((int)v);
@@ -199,6 +203,7 @@ struct Smem {
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
     uint32_t lbacc[11][2];         // per candidate: block sums of Thread::lb_g / lb_aux (pruning bound)
+    uint32_t has4[2];              // current candidate has a run of >= 4 zero residuals (zero-run mode possible)
     uint64_t wtotP[16];  // per-wave totals used by the block scans
     int32_t wtotZ[16];
     uint32_t wtotF[16];
@@ -221,6 +226,7 @@ struct Thread {
     uint32_t chasrun;
     uint32_t lb_g;    // sum over the chunk of bit_width(u)+1 (per-sample floor of any Rice code)
     uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16
+    uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
 };
 
 template <class G>
@@ -518,6 +524,7 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
     uint64_t P = sh.tabP[th.tid];
     uint32_t cnt = 0;
     uint32_t c = (uint32_t)th.a;
+    uint32_t zm = 0;  // bit i: sample i of the chunk is zero
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t u = sh.u[i * G::T + th.tid];
         P += u;
@@ -527,8 +534,15 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
         const uint32_t fl = q > 3u, fz = q == 0u;
         sh.u[i * G::T + th.tid] = u | (fl << 30) | (fz << 31);
         cnt += fl + (fz << 16);
+        zm |= (u == 0u ? 1u : 0u) << i;
     }
     sh.tabF[th.tid] = cnt;
+    // Zero-run mode can only matter when some run of >= 4 zeros exists (ref block/encoder.cpp:224-247 sets
+    // has_run only then).  Such a run lies inside one chunk, or crosses into a chunk: then the zeros ending
+    // just before the chunk plus the chunk's leading zeros reach 4.
+    const uint32_t lead = (uint32_t)ctz32(~zm);
+    const int32_t before = th.a - 1 - sh.tabNZ[th.tid];
+    th.has4 = (th.cnt > 0 && ((zm & (zm >> 1) & (zm >> 2) & (zm >> 3)) != 0u || (uint32_t)before + lead >= 4u)) ? 1u : 0u;
 }
 
 // Sample j as seen by the zero-run lookahead: its u, or 1 ("not a zero") at/after `limit`.
@@ -542,7 +556,7 @@ LACX_HD uint32_t peek_u(const M& sh, uint32_t j, uint32_t limit) {
 
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
 // (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
-template <class G, bool NARROW>
+template <class G, bool NARROW, bool ZR = true>
 LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     const int t = th.tid;
     const uint32_t n = th.n;
@@ -571,16 +585,18 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
         rice += rc;
         bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
-        const bool z = (u == 0);
-        f = z ? f + 1 : 0;
-        const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-        const bool in4 = z & (f + ahead >= 4);
-        const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-        const uint32_t plain = 2u + ((u > esc) ? 32u : rc);              // not inside a run of >= 4
-        const uint32_t token = 5u + (((uint32_t)(f - 4)) >> 2);          // last sample of such a run
-        const bool runend = in4 & (n1 != 0);
-        zr += in4 ? (runend ? token : 0u) : plain;
-        hasrun |= runend ? 1u : 0u;
+        if (ZR) {
+            const bool z = (u == 0);
+            f = z ? f + 1 : 0;
+            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+            const bool in4 = z & (f + ahead >= 4);
+            const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+            const uint32_t plain = 2u + ((u > esc) ? 32u : rc);              // not inside a run of >= 4
+            const uint32_t token = 5u + (((uint32_t)(f - 4)) >> 2);          // last sample of such a run
+            const bool runend = in4 & (n1 != 0);
+            zr += in4 ? (runend ? token : 0u) : plain;
+            hasrun |= runend ? 1u : 0u;
+        }
         // state after this sample -> k for the next one
         P += u;
         ++c;
@@ -591,9 +607,11 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
         // slide the lookahead window
         w0 = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
-        n1 = n2;
-        n2 = n3;
-        n3 = peek_u<G>(sh, (uint32_t)(th.a + i) + 4u, n);
+        if (ZR) {
+            n1 = n2;
+            n2 = n3;
+            n3 = peek_u<G>(sh, (uint32_t)(th.a + i) + 4u, n);
+        }
     }
     th.crice = rice;
     th.cbin = bin;
@@ -821,7 +839,7 @@ LACX_HD bool partitions_chunk_aligned(uint32_t n, int max_p) {
 
 // All partition orders in one pass (32-bit arithmetic: requires total sum of u < 2^31).
 // Same numbers as partition_pass<G, true> run for p = 1..max_p.
-template <class G, class Flush>
+template <class G, bool ZR = true, class Flush>
 LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, Flush&& flush) {
     if (th.cnt <= 0) return;
     const uint32_t n = th.n;
@@ -865,16 +883,18 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
                 const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
                 rice[q] += rc;
                 bin[q] += is_small ? small : 2u + rc;
-                const uint32_t left = rem[q] - 1u - (uint32_t)i;          // samples after j inside the partition
-                const uint32_t fp = ((uint32_t)fg < cbefore + 1u) ? (uint32_t)fg : cbefore + 1u;
-                const uint32_t ahead = ahead_g < left ? ahead_g : left;
-                const bool in4 = z & (fp + ahead >= 4u);
-                const bool runend = in4 & (ahead == 0u);
-                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-                const uint32_t plain = 2u + ((u > esc) ? 32u : rc);
-                const uint32_t token = 5u + ((fp - 4u) >> 2);
-                zr[q] += in4 ? (runend ? token : 0u) : plain;
-                hasrun |= runend ? (1u << q) : 0u;
+                if (ZR) {
+                    const uint32_t left = rem[q] - 1u - (uint32_t)i;          // samples after j inside the partition
+                    const uint32_t fp = ((uint32_t)fg < cbefore + 1u) ? (uint32_t)fg : cbefore + 1u;
+                    const uint32_t ahead = ahead_g < left ? ahead_g : left;
+                    const bool in4 = z & (fp + ahead >= 4u);
+                    const bool runend = in4 & (ahead == 0u);
+                    const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+                    const uint32_t plain = 2u + ((u > esc) ? 32u : rc);
+                    const uint32_t token = 5u + ((fp - 4u) >> 2);
+                    zr[q] += in4 ? (runend ? token : 0u) : plain;
+                    hasrun |= runend ? (1u << q) : 0u;
+                }
             }
         }
         P += u;

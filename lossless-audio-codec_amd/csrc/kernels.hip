@@ -531,6 +531,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     }
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
     if (tid < 22) (&sh.lbacc[0][0])[tid] = 0;
+    if (tid < 2) sh.has4[tid] = 0;
     if (tid == 0) sh.best_cand = -1;
     __syncthreads();
     STAMP(0);
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
             score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
             for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
             for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
+            sh.has4[parity ^ 1] = 0;
             pending = -1;
         }
         STAMP(1);
@@ -591,11 +593,13 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
         if (prm.debug_skip & 2u) {
             sh.tabF[tid] = 0;
+            th.has4 = 1u;
         } else if (narrow) {
             phase_a<G, true>(th, sh);
         } else {
             phase_a<G, false>(th, sh);
         }
+        if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B4
         STAMP(8);
         uint32_t fown;
         const uint32_t finc = scan_f_part1<G>(sh, tid, fown);
@@ -609,10 +613,14 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         if (prm.debug_skip & 4u) {
             th.crice = th.cbin = th.czr = 1;
             th.chasrun = 0;
-        } else if (narrow) {
-            phase_b<G, true>(th, sh, k0);
         } else {
-            phase_b<G, false>(th, sh, k0);
+            // the zero-run cost only matters when the residual has a run of >= 4 zeros somewhere
+            const bool zr = prm.zero_run && sh.has4[parity] != 0u;
+            if (narrow) {
+                if (zr) phase_b<G, true, true>(th, sh, k0); else phase_b<G, true, false>(th, sh, k0);
+            } else {
+                if (zr) phase_b<G, false, true>(th, sh, k0); else phase_b<G, false, false>(th, sh, k0);
+            }
         }
         STAMP(12);
         {
@@ -693,7 +701,10 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         if (prm.debug_skip & 8u) {
             // (timing ablation only)
         } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
-            partition_fused<G>(th, sh, max_p, flush);  // all orders in one walk (every full block, every probe)
+            // all orders in one walk (every full block, every probe); without a run of >= 4 zeros in the
+            // block no partition can have one, so the zero-run costs are not needed
+            if (prm.zero_run && sh.best_hasrun) partition_fused<G, true>(th, sh, max_p, flush);
+            else partition_fused<G, false>(th, sh, max_p, flush);
         } else {
             for (int p = 1; p <= max_p; ++p) {
                 if (pnarrow) {

@@ -102,8 +102,15 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
             sh.tabF[G::T] = run;
         }
         sh.acc[0][0] = sh.acc[0][1] = sh.acc[0][2] = sh.acc[0][3] = 0;
+        bool zr = false;
+        for (int t = 0; t < G::T; ++t) zr = zr || th[t].has4 != 0;
+        zr = zr && zero_run;
         for (int t = 0; t < G::T; ++t) {
-            if (narrow) phase_b<G, true>(th[t], sh, k0); else phase_b<G, false>(th[t], sh, k0);
+            if (narrow) {
+                if (zr) phase_b<G, true, true>(th[t], sh, k0); else phase_b<G, true, false>(th[t], sh, k0);
+            } else {
+                if (zr) phase_b<G, false, true>(th[t], sh, k0); else phase_b<G, false, false>(th[t], sh, k0);
+            }
             if ((uint32_t)th[t].a < n) {
                 sh.acc[0][0] += th[t].crice;
                 sh.acc[0][1] += th[t].cbin;
@@ -153,7 +160,8 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         const bool fused = pnarrow && !(force_wide & 2) && partitions_chunk_aligned<G>(n, max_p);
         for (int t = 0; t < G::T; ++t) {
             if (fused) {
-                partition_fused<G>(th[t], sh, max_p, flush);
+                if (zero_run && sh.best_hasrun) partition_fused<G, true>(th[t], sh, max_p, flush);
+                else partition_fused<G, false>(th[t], sh, max_p, flush);
                 continue;
             }
             for (int p = 1; p <= max_p; ++p) {
