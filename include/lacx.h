@@ -13,6 +13,9 @@
  *                                                            ref block/encoder.cpp:313-552, lac/encoder.cpp:126-197,321-373
  *   lacx_emit_from_plans   <- the emit half of Block::Encoder::encode + container write
  *                                                            ref block/encoder.cpp:554-838, lac/encoder.cpp:243-250,445-465
+ *   lacx_wav_parse /
+ *   lacx_encode_wav        <- read_wav + LAC::Encoder::encode as chained by the CLI
+ *                                                            ref src/io/wav_io.cpp:167-277, src/main.cpp:640-675
  *   lacx_encode_shard /
  *   lacx_assemble          <- the block loop + block table concat of LAC::Encoder::encode, split so that
  *                             contiguous block ranges can be encoded by different GPUs/processes
@@ -155,6 +158,23 @@ typedef struct lacx_pcm {
 int lacx_encode_shard_pcm_device_view(lacx_encoder* enc, const lacx_pcm* d_pcm, uint64_t frames, void* stream,
                                       const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
                                       uint32_t* nblocks);
+
+/* WAV ingest (replaces read_wav + LAC::Encoder::encode of the CLI's encode command,
+ * ref src/io/wav_io.cpp:167-277, src/main.cpp:640-675).  lacx_wav_parse walks the RIFF container in memory and
+ * accepts / rejects exactly the files read_wav does (LACX_OK / LACX_E_INVALID, no device needed); lacx_encode_wav
+ * copies the raw data chunk to the device as it is (2 or 3 bytes per sample), the kernels de-interleave and
+ * sign-extend on load, and the complete .lac comes back -- the bytes the reference produces from the same file.
+ * The encoder's sample_rate and bit_depth must match the file's. */
+typedef struct lacx_wav_info {
+    uint16_t channels;
+    uint16_t bit_depth;
+    uint32_t sample_rate;
+    uint64_t frames;
+    uint64_t data_offset; /* byte offset of the first sample in the file */
+    uint64_t data_bytes;
+} lacx_wav_info;
+int lacx_wav_parse(const uint8_t* wav, uint64_t size, lacx_wav_info* out);
+int lacx_encode_wav(lacx_encoder* enc, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size);
 
 /* Host-only: header + block table + payload concat of shards given in stream order. */
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,

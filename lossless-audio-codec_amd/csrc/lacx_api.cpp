@@ -19,6 +19,7 @@
 
 #include "emit.h"
 #include "kernels.h"
+#include "wav_parse.h"
 #include "lacx.h"
 
 using namespace lacx;
@@ -52,6 +53,8 @@ struct lacx_encoder {
     // device emit
     uint8_t* d_payload = nullptr;
     uint64_t d_payload_cap = 0;
+    uint8_t* d_raw = nullptr;  // WAV data chunk as read from the file (lacx_encode_wav)
+    uint64_t d_raw_cap = 0;
     uint8_t* h_payload = nullptr;  // pinned
     uint64_t h_payload_cap = 0;
     uint32_t* h_table = nullptr;   // pinned, [blocks][2]
@@ -693,6 +696,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         for (auto& ev : e->copied)
             if (ev) (void)hipEventDestroy(ev);
         if (e->d_payload) (void)hipFree(e->d_payload);
+        if (e->d_raw) (void)hipFree(e->d_raw);
         if (e->h_payload) (void)hipHostFree(e->h_payload);
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -988,6 +992,56 @@ int lacx_encode_shard(lacx_encoder* e, const int32_t* left, const int32_t* right
     if (rc) return rc;
     return lacx_encode_shard_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr,
                                     payload, payload_size, table, nblocks);
+}
+
+int lacx_wav_parse(const uint8_t* wav, uint64_t size, lacx_wav_info* out) {
+    if (!wav || !out) return LACX_E_INVALID;
+    WavInfo w;
+    if (!wav_parse(wav, size, &w)) return LACX_E_INVALID;
+    out->channels = w.channels;
+    out->bit_depth = w.bit_depth;
+    out->sample_rate = w.sample_rate;
+    out->frames = w.frames;
+    out->data_offset = w.data_offset;
+    out->data_bytes = w.data_bytes;
+    return LACX_OK;
+}
+
+int lacx_encode_wav(lacx_encoder* e, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    e->timing = lacx_timing{};
+    WavInfo w;
+    if (!wav || !wav_parse(wav, size, &w)) return fail(e, LACX_E_INVALID, "not a supported PCM WAV file");
+    if (w.sample_rate != e->cfg.sample_rate || w.bit_depth != e->cfg.bit_depth)
+        return fail(e, LACX_E_INVALID, "WAV format (" + std::to_string(w.sample_rate) + " Hz, " +
+                                           std::to_string((int)w.bit_depth) + " bit) differs from the encoder's");
+    int rc = prepare(e, wav + w.data_offset, w.frames);
+    if (rc) return rc;
+    if (w.data_bytes + 16u > e->d_raw_cap) {
+        if (e->d_raw) (void)hipFree(e->d_raw);
+        e->d_raw = nullptr;
+        e->d_raw_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_raw, w.data_bytes + 16u), "hipMalloc(wav data)");
+        e->d_raw_cap = w.data_bytes + 16u;
+    }
+    // the data chunk as it is in the file: interleaved little-endian int16 / packed int24 (coalesced ingest)
+    HIP_TRY(e, hipMemcpy(e->d_raw, wav + w.data_offset, w.data_bytes, hipMemcpyHostToDevice), "H2D wav data");
+    e->timing.h2d_ms = ms_since(t0);
+    const int layout = w.bit_depth == 16 ? (int)LACX_PCM_INTERLEAVED_I16 : (int)LACX_PCM_INTERLEAVED_I24;
+    uint64_t pay = 0;
+    rc = encode_pipelined_device(e, reinterpret_cast<const int32_t*>(e->d_raw), nullptr, w.frames, nullptr, &pay, layout,
+                                 (int)w.channels);
+    if (rc == -1) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
+    if (rc) return rc;
+    const uint8_t* payloads[1] = {e->h_payload};
+    const uint64_t sizes[1] = {pay};
+    const uint32_t* tables[1] = {e->h_table};
+    const uint32_t nbs[1] = {blocks_for(w.frames)};
+    rc = lacx_assemble(&e->cfg, (int)w.channels, 1, payloads, sizes, tables, nbs, out, out_size);
+    if (rc) return fail(e, rc, "container assembly failed");
+    e->timing.total_ms = ms_since(t0);
+    return LACX_OK;
 }
 
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,

@@ -84,7 +84,8 @@ EXPORTS = (
     "lacx_encoder_create", "lacx_encoder_destroy", "lacx_last_error", "lacx_free", "lacx_get_timing",
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
-    "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count",
+    "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
+    "lacx_encode_wav",
 )
 
 
@@ -310,6 +311,21 @@ class Encoder:
         table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))
         return PayloadView(pay, psize.value), table
 
+    def encode_wav(self, wav: bytes) -> bytes:
+        """Complete .lac of a PCM WAV file image: the raw data chunk goes to the device as it is (ref
+        src/io/wav_io.cpp:167-277 + src/main.cpp:640-675 chained)."""
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._handle()
+        buf = (C.c_uint8 * len(wav)).from_buffer_copy(wav)
+        rc = lib().lacx_encode_wav(h, buf, C.c_uint64(len(wav)), C.byref(out), C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        try:
+            return C.string_at(out, size.value)
+        finally:
+            lib().lacx_free(out)
+
     def encode_shard_pcm_device_view(self, data_ptr: int, layout: int, channels: int, frames: int, stream: int = 0):
         """Zero-copy shard encode of device-resident PCM in its source layout (interleaved int16 / int24)."""
         pcm = Pcm(data_ptr, None, layout, channels)
@@ -394,6 +410,20 @@ class Payload:
                 self._ptr = None
         except Exception:
             pass
+
+
+class WavInfo(C.Structure):
+    _fields_ = [("channels", C.c_uint16), ("bit_depth", C.c_uint16), ("sample_rate", C.c_uint32),
+                ("frames", C.c_uint64), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64)]
+
+
+def wav_parse(wav: bytes):
+    """RIFF walk with the reference's accept/reject rules (ref src/io/wav_io.cpp:167-277); None when rejected.
+    Host-only: needs no device."""
+    info = WavInfo()
+    buf = (C.c_uint8 * max(1, len(wav))).from_buffer_copy(wav if wav else b"\0")
+    rc = lib().lacx_wav_parse(buf, C.c_uint64(len(wav)), C.byref(info))
+    return info if rc == OK else None
 
 
 def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:

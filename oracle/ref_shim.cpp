@@ -25,6 +25,7 @@
 #include "codec/lac/encoder.hpp"
 #include "codec/lpc/lpc.hpp"
 #include "codec/rice/rice.hpp"
+#include "io/wav_io.hpp"
 
 namespace {
 thread_local std::string g_last_error;
@@ -134,6 +135,24 @@ void lacref_adapt_k_sequence(const uint32_t* u, uint32_t n, uint32_t* k_out) {
         sum += u[i];
         k_out[i] = Rice::adapt_k(sum, i + 1, st);
     }
+}
+
+// read_wav (ref src/io/wav_io.cpp:167-277) on a file path.  Returns 1 when the reference accepts the file and
+// fills the format fields; left/right (caller buffers of `cap` samples each, may be NULL) receive the samples.
+int lacref_read_wav(const char* path, uint16_t* channels, uint32_t* sample_rate, uint8_t* bit_depth, uint64_t* frames,
+                    int32_t* left, int32_t* right, uint64_t cap) {
+    std::vector<int32_t> l, r;
+    uint16_t ch = 0;
+    uint32_t sr = 0;
+    uint8_t bd = 0;
+    if (!read_wav(path, l, r, ch, sr, bd)) return 0;
+    *channels = ch;
+    *sample_rate = sr;
+    *bit_depth = bd;
+    *frames = l.size();
+    if (left && l.size() <= cap) std::memcpy(left, l.data(), l.size() * sizeof(int32_t));
+    if (right && r.size() <= cap && !r.empty()) std::memcpy(right, r.data(), r.size() * sizeof(int32_t));
+    return 1;
 }
 
 }  // extern "C"

@@ -106,3 +106,18 @@ def adapt_k_sequence(u):
     lib().lacref_adapt_k_sequence(U.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(U.size),
                                   out.ctypes.data_as(C.POINTER(C.c_uint32)))
     return out
+
+
+def read_wav(path: str):
+    """Reference read_wav: None when rejected, else (left, right_or_None, channels, sample_rate, bit_depth)."""
+    ch, sr, bd, fr = C.c_uint16(), C.c_uint32(), C.c_uint8(), C.c_uint64()
+    cap = max(1, os.path.getsize(path))
+    left = np.zeros(cap, dtype=np.int32)
+    right = np.zeros(cap, dtype=np.int32)
+    ok = lib().lacref_read_wav(path.encode(), C.byref(ch), C.byref(sr), C.byref(bd), C.byref(fr),
+                               left.ctypes.data_as(C.POINTER(C.c_int32)), right.ctypes.data_as(C.POINTER(C.c_int32)),
+                               C.c_uint64(cap))
+    if not ok:
+        return None
+    n = fr.value
+    return left[:n].copy(), (right[:n].copy() if ch.value == 2 else None), ch.value, sr.value, bd.value

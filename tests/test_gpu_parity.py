@@ -249,3 +249,20 @@ def test_unaligned_device_pointers(gpu, oracle, bd):
     dr[1:] = torch.from_numpy(right).cuda()
     torch.cuda.synchronize()
     assert enc.encode_device(dl.data_ptr() + 4, dr.data_ptr() + 4, left, right, frames) == want
+
+
+def test_encode_wav_matches_reference_chain(gpu, oracle):
+    """lacx_encode_wav == read_wav + LAC::Encoder::encode (raw data chunk to the device, ingest on load)."""
+    import wavutil as W
+
+    l16, r16 = gpu.synth.synth_pcm(16384 * 2 + 999, 2, 16, 48000, seed=31, kind="music")
+    l24, _ = gpu.synth.synth_pcm(16384 + 5, 1, 24, 96000, seed=32, kind="mixed")
+    odd = W.chunk(b"LIST", b"abc")
+    wav = W.make_wav(l16, r16, 48000, 16, before=[odd], after=[odd])
+    assert gpu.lacx.Encoder(12, 2, 48000, 16).encode_wav(wav) == oracle.encode(l16, r16, 48000, 16, 2, threads=8)
+    wav = W.make_wav(l24, None, 96000, 24, between=[W.chunk(b"fact", b"12345")])
+    assert gpu.lacx.Encoder(12, 0, 96000, 24).encode_wav(wav) == oracle.encode(l24, None, 96000, 24, 0, threads=8)
+    with pytest.raises(ValueError, match="differs from the encoder"):
+        gpu.lacx.Encoder(12, 0, 48000, 24).encode_wav(wav)
+    with pytest.raises(ValueError, match="not a supported PCM WAV"):
+        gpu.lacx.Encoder(12, 0, 48000, 24).encode_wav(wav[:-1])
