@@ -52,6 +52,11 @@ DIGESTS = [
     ("mono_30s_16_44k", 1_323_000, 1, 16, 44100, 0, "mixed", "wide", 5, True, True),
     ("forced_ms_20s_24_192k", 3_840_000, 2, 24, 192000, 1, "music", "narrow", 9, False, True),
     ("forced_lr_20s_16_96k", 1_920_000, 2, 16, 96000, 0, "mixed", "wide", 11, False, True),
+    # BASELINE configs[3]: 2 h stereo 16/48 (21 094 blocks) split in 8 contiguous block ranges; this is the last
+    # range [18457, 21094) -- 2637 blocks incl. the 12 288-frame final block -- encoded as a stream of its own
+    # (blocks are independent, so payload and table equal that range of the whole stream's).
+    ("cfg4_2h_shard8of8_st16_48k", 345_600_000 - 18457 * 16384, 2, 16, 48000, 2, "music", "wide", 2026, False, True,
+     18457 * 16384),
 ]
 
 
@@ -72,13 +77,15 @@ def main():
     with open(os.path.join(HERE, "small", "index.json"), "w") as f:
         json.dump(index, f, indent=1)
     out = []
-    for name, frames, ch, bd, sr, sm, kind, st, seed, cpu_test, gpu_test in DIGESTS:
-        left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st)
+    for ent in DIGESTS:
+        name, frames, ch, bd, sr, sm, kind, st, seed, cpu_test, gpu_test = ent[:11]
+        start = ent[11] if len(ent) > 11 else 0
+        left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st, start=start)
         data = refshim.encode(left, right, sr, bd, sm)
         out.append(dict(name=name, stereo_mode=sm, lac_bytes=len(data), lac_sha256=hashlib.sha256(data).hexdigest(),
                         cpu_test=cpu_test, gpu_test=gpu_test,
                         gen=dict(frames=frames, channels=ch, bit_depth=bd, sample_rate=sr, seed=seed, kind=kind,
-                                 stereo=st)))
+                                 stereo=st, start=start)))
         print(name, len(data), out[-1]["lac_sha256"][:16])
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(out, f, indent=1)

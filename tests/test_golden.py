@@ -38,7 +38,7 @@ def test_digests(pkg, oracle):
             continue
         g = ent["gen"]
         left, right = pkg.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"],
-                                          seed=g["seed"], kind=g["kind"], stereo=g["stereo"])
+                                          seed=g["seed"], kind=g["kind"], stereo=g["stereo"], start=g.get("start", 0))
         got = oracle.encode(left, right, g["sample_rate"], g["bit_depth"], ent["stereo_mode"], threads=8)
         assert len(got) == ent["lac_bytes"], ent["name"]
         assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], ent["name"]

@@ -178,7 +178,8 @@ def test_golden_digests(gpu):
             continue
         g = ent["gen"]
         left, right = gpu.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"],
-                                          seed=g["seed"], kind=g["kind"], stereo=g.get("stereo", "wide"))
+                                          seed=g["seed"], kind=g["kind"], stereo=g.get("stereo", "wide"),
+                                          start=g.get("start", 0))
         for host_emit in (False, True):
             enc = gpu.lacx.Encoder(12, ent["stereo_mode"], g["sample_rate"], g["bit_depth"])
             enc.set_host_emit(host_emit)
@@ -266,3 +267,18 @@ def test_encode_wav_matches_reference_chain(gpu, oracle):
         gpu.lacx.Encoder(12, 0, 48000, 24).encode_wav(wav)
     with pytest.raises(ValueError, match="not a supported PCM WAV"):
         gpu.lacx.Encoder(12, 0, 48000, 24).encode_wav(wav[:-1])
+
+
+def test_config5_every_format_combination(gpu, oracle):
+    """BASELINE configs[4]: {mono, stereo} x {16, 24 bit} x {44.1, 48, 96, 192 kHz} as one batched job through one
+    process: per-block predictor choice + stereo auto-select for every combination, bytes equal to the oracle's."""
+    seed = 100
+    for ch in (1, 2):
+        for bd in (16, 24):
+            for sr in (44100, 48000, 96000, 192000):
+                seed += 1
+                frames = sr * 2 + 321
+                left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind="mixed" if seed & 1 else "music")
+                sm = 2 if ch == 2 else 0
+                got = gpu.lacx.Encoder(12, sm, sr, bd).encode(left, right)
+                assert got == oracle.encode(left, right, sr, bd, sm, threads=8), (ch, bd, sr)
