@@ -95,6 +95,15 @@ LACX_HD int32_t slot_fetch(const SlotSrc& s, int64_t idx) {
 
 LACX_HD uint32_t zigzag32(int32_t r) { return ((uint32_t)r << 1) ^ (uint32_t)(r >> 31); }
 
+// Optimisation barrier on a per-thread value (device builds): what is derived from the result cannot be hoisted
+// out of an enclosing loop.  Used where hoisting only lengthens live ranges and, at 128 VGPRs, ends in spills.
+LACX_HD int opaque_i32(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 LACX_HD int ctz32(uint32_t v) {  // v != 0
     return __builtin_ctz(v);
 }

@@ -280,6 +280,21 @@ __device__ __forceinline__ void reduce13(const int64_t* acc, unsigned long long*
     __syncthreads();
 }
 
+// XCD-aware slot mapping.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, so ids w and w + 8
+// share an XCD and its L2.  The `per` workgroups that work on the same block (its channels) all read the same
+// PCM, so they get ids 8 apart: the block is fetched from HBM once and the other reads hit that L2.
+// Ids beyond the last full group of 8 blocks fall back to the plain (w / per, w % per) mapping.
+__device__ __forceinline__ void xcd_slot(uint32_t w, uint32_t per, uint32_t nblocks, uint32_t& blk, uint32_t& which) {
+    const uint32_t group = 8u * per, g = w / group, r = w % group;
+    if (g < nblocks / 8u) {
+        blk = g * 8u + (r & 7u);
+        which = r >> 3;
+    } else {
+        blk = w / per;
+        which = w % per;
+    }
+}
+
 __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __restrict__ L,
                                                            const int32_t* __restrict__ R, AnalyzeParams prm,
                                                            unsigned long long* __restrict__ sums,
@@ -289,8 +304,9 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     __shared__ unsigned long long s_ac[13];
     __shared__ unsigned long long s_sum[3];
     __shared__ unsigned int s_bad;
-    const uint32_t blk = blockIdx.x >> 2;
-    const int ch = (int)(blockIdx.x & 3u);
+    uint32_t blk, chsel;
+    xcd_slot(blockIdx.x, 4u, gridDim.x >> 2, blk, chsel);
+    const int ch = (int)chsel;
     const bool used = slot_channel_used(prm, ch);
     // forced mid/side still validates the left/right samples (ref lac/encoder.cpp:238-241)
     const bool validate = ch < 2 && ch < prm.channels && prm.bit_depth != 0;
@@ -475,45 +491,13 @@ __global__ __launch_bounds__(64) void k_levinson(AnalyzeParams prm, const int64_
 // ---------------------------------------------------------------------------------------------
 // k_analyze
 // ---------------------------------------------------------------------------------------------
+// The analysis of one slot (everything after the slot has been picked).
 template <class G>
-__global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
-                                                  AnalyzeParams prm, int probe_class, uint32_t blk_offset,
-                                                  int which_base, const LpcSet* __restrict__ lpcs,
-                                                  const uint32_t* __restrict__ need,
-                                                  ChannelPlan* __restrict__ plans) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const AnalyzeParams& prm, uint32_t n_in,
+                                             const SlotSrc& src, int64_t start, const LpcSet* __restrict__ lpc_slot,
+                                             ChannelPlan* __restrict__ plan_out, const int tid) {
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
-    const int tid = threadIdx.x;
-    // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
-    // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
-    // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
-    uint32_t blk;
-    int slot = -1;
-    if (probe_class) {
-        blk = blockIdx.x / 12u;
-        const int s = 4 + (int)(blockIdx.x % 12u);
-        if ((need[blk] >> s) & 1u) slot = s;
-    } else {
-        const uint32_t per = prm.channels == 2 ? 2u : 1u;
-        blk = blk_offset + blockIdx.x / per;
-        int which = (int)(blockIdx.x % per) + which_base;
-        uint32_t m = need[blk] & 0xFu;
-        while (m) {
-            const int s = __ffs((int)m) - 1;
-            if (which == 0) {
-                slot = s;
-                break;
-            }
-            --which;
-            m &= m - 1u;
-        }
-    }
-    if (slot < 0) return;  // uniform for the workgroup
-    const SlotGeom g = slot_geom(prm, blk, slot);
-    const uint32_t n = g.n;
-    const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
-    const SlotSrc src = slot_src(prm, L, R, slot & 3);
-
+    const uint32_t n = n_in;
 #ifdef LACX_STAMPS
     unsigned long long stamp_acc[24];
     for (int k = 0; k < 24; ++k) stamp_acc[k] = 0;
@@ -522,9 +506,9 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
 #endif
     Thread<G> th;
     thread_init(th, n, tid);
-    stage_samples(th, sh, src, g.start);
+    stage_samples(th, sh, src, start);
     for (int i = tid; i < (int)(sizeof(LpcSet) / 2); i += G::T)
-        reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(&lpcs[sidx])[i];
+        reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(lpc_slot)[i];
     if (tid < 32) {
         sh.planeTot[0][tid] = sh.planeTot[1][tid] = 0;
         sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
@@ -542,6 +526,10 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     for (int ci = 0; ci <= 10; ++ci) {
         const int cand = candidate_at(ci);
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
+        // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
+        // addresses and masks derived from it out of this loop and, at the 128-VGPR budget, spills them to scratch.
+        asm volatile("" : "+v"(th.a));
+
         if (cand >= 6 && (prm.debug_skip & 16u)) continue;
         if (cand >= 1 && (prm.debug_skip & 64u)) continue;
         uint32_t* pt = sh.planeTot[parity];
@@ -724,7 +712,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         }
         __syncthreads();
     }
-    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &plans[sidx]);
+    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, plan_out);
     STAMP(21);
 #ifdef LACX_STAMPS
     if ((tid & 63) == 0 && G::T == 1024) {
@@ -733,6 +721,49 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         atomicAdd(&g_stamp_acc[24], 1ull);
     }
 #endif
+}
+
+template <class G>
+__global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
+                                                  AnalyzeParams prm, int probe_class, uint32_t blk_offset,
+                                                  int which_base, const LpcSet* __restrict__ lpcs,
+                                                  const uint32_t* __restrict__ need,
+                                                  ChannelPlan* __restrict__ plans) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
+    // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
+    // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
+    uint32_t blk;
+    int slot = -1;
+    if (probe_class) {
+        blk = blockIdx.x / 12u;
+        const int s = 4 + (int)(blockIdx.x % 12u);
+        if ((need[blk] >> s) & 1u) slot = s;
+    } else {
+        const uint32_t per = prm.channels == 2 ? 2u : 1u;
+        uint32_t wsel;
+        xcd_slot(blockIdx.x, per, (prm.debug_skip & 512u) ? 0u : gridDim.x / per, blk, wsel);
+        blk += blk_offset;
+        int which = (int)wsel + which_base;
+        uint32_t m = need[blk] & 0xFu;
+        while (m) {
+            const int s = __ffs((int)m) - 1;
+            if (which == 0) {
+                slot = s;
+                break;
+            }
+            --which;
+            m &= m - 1u;
+        }
+    }
+    if (slot < 0) return;  // uniform for the workgroup
+    const SlotGeom g = slot_geom(prm, blk, slot);
+    const uint32_t n = g.n;
+    const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
+    const SlotSrc src = slot_src(prm, L, R, slot & 3);
+
+    analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -855,8 +886,9 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     __shared__ int32_t s_wx[16];
     const int tid = threadIdx.x;
     const uint32_t per = prm.channels == 2 ? 2u : 1u;
-    const uint32_t blk = blockIdx.x / per;
-    const int which = (int)(blockIdx.x % per);
+    uint32_t blk, wsel;
+    xcd_slot(blockIdx.x, per, gridDim.x / per, blk, wsel);
+    const int which = (int)wsel;
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
     const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
