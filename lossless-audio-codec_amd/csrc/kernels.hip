@@ -479,13 +479,31 @@ __global__ __launch_bounds__(64) void k_levinson(AnalyzeParams prm, const int64_
         if (prm.stereo_mode == 0 && (slot & 3) >= 2) return;
         if (prm.stereo_mode == 1 && (slot & 3) < 2) return;
     }
-    int64_t r[13];
-    for (int k = 0; k < 13; ++k) r[k] = acorr[(size_t)gid * 13 + k];
     const int mvo = (g.n > 1) ? (int)((g.n - 1 < 32u) ? g.n - 1 : 32u) : 0;
-    LpcSet out;
-    levinson_candidates(r, mvo, out.coef, out.used);
-    out.pad = 0;
-    lpcs[gid] = out;
+    // work arrays in LDS, one column per thread (indexed by loop variables: as locals they would be scratch)
+    __shared__ uint64_t s_m[3][13][64];
+    __shared__ int32_t s_e[3][13][64];
+    __shared__ uint32_t s_s[3][13][64];
+    struct LdsArray {
+        uint64_t (*m)[64];
+        int32_t (*e)[64];
+        uint32_t (*s)[64];
+        int lane;
+        __device__ xf80 get(int i) const { return xf80{m[i][lane], e[i][lane], s[i][lane]}; }
+        __device__ void set(int i, xf80 x) {
+            m[i][lane] = x.m;
+            e[i][lane] = x.e;
+            s[i][lane] = x.s;
+        }
+    };
+    const int lane = (int)threadIdx.x;
+    LdsArray Rv{s_m[0], s_e[0], s_s[0], lane}, av{s_m[1], s_e[1], s_s[1], lane}, pv{s_m[2], s_e[2], s_s[2], lane};
+    const int64_t* r = acorr + (size_t)gid * 13;
+    LpcSet* out = &lpcs[gid];
+    levinson_candidates_t([r](int i) { return r[i]; }, mvo, Rv, av, pv,
+                          [out](int ci, int j, int16_t v) { out->coef[ci][j] = v; },
+                          [out](int ci, uint8_t v) { out->used[ci] = v; });
+    out->pad = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

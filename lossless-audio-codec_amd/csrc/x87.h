@@ -281,43 +281,49 @@ LACX_HD xf80 xf_const_one() { return xf80{0x8000000000000000ull, 0, 0}; }
 // order, so the order-c solve is the order-12 solve stopped after c iterations.
 // r[0..12]: exact integer autocorrelation. max_order: highest candidate to produce (<= 12).
 // out_coef[ci][0..12], out_used[ci] for ci over cands {4,6,8,10,12}.
-LACX_HD void levinson_candidates(const int64_t* r, int max_valid_order, int16_t out_coef[5][13],
-                                 uint8_t out_used[5]) {
+//
+// The three 13-element work arrays are reached through an accessor so that the device kernel can keep them in
+// LDS (one column per thread): indexed by loop variables, plain local arrays would live in scratch memory and
+// every access would pay a trip through the vector memory path.
+struct XfLocalArray {
+    xf80 v[13];
+    LACX_HD xf80 get(int i) const { return v[i]; }
+    LACX_HD void set(int i, xf80 x) { v[i] = x; }
+};
+
+template <class Arr, class GetR, class PutCoef, class PutUsed>
+LACX_HD void levinson_candidates_t(GetR&& get_r, int max_valid_order, Arr& R, Arr& a, Arr& prevA, PutCoef&& put_coef,
+                                   PutUsed&& put_used) {
     const xf80 eps = xf_const_1em8();
     const xf80 lim = xf_const_0_999();
     const xf80 one = xf_const_one();
-    xf80 R[13], a[13], prevA[13];
     for (int i = 0; i <= 12; ++i) {
-        R[i] = xf_from_i64(r[i]);
-        a[i] = xf_zero();
-        prevA[i] = xf_zero();
+        R.set(i, xf_from_i64(get_r(i)));
+        a.set(i, xf_zero());
+        prevA.set(i, xf_zero());
     }
-    if (xf_lt(R[0], one)) R[0] = one;  // lpc.cpp:169-172 (energy < 1 -> 1)
-    for (int ci = 0; ci < 5; ++ci) {
-        out_used[ci] = 0;
-        for (int j = 0; j <= 12; ++j) out_coef[ci][j] = 0;
-    }
-    xf80 E = R[0];
+    if (xf_lt(R.get(0), one)) R.set(0, one);  // lpc.cpp:169-172 (energy < 1 -> 1)
+    xf80 E = R.get(0);
     int achieved = 0;
     bool stopped = xf_lt(E, eps);  // lpc.cpp:105-109 (cannot trigger after the clamp to 1)
     int next_ci = 0;
     for (int i = 1; i <= 12; ++i) {
         if (!stopped) {
             xf80 acc = xf_zero();
-            for (int j = 1; j < i; ++j) acc = xf_add(acc, xf_mul(prevA[j], R[i - j]));
+            for (int j = 1; j < i; ++j) acc = xf_add(acc, xf_mul(prevA.get(j), R.get(i - j)));
             if (xf_lt(E, eps)) {
                 stopped = true;
             } else {
-                xf80 ki = xf_div(xf_sub(R[i], acc), E);
+                xf80 ki = xf_div(xf_sub(R.get(i), acc), E);
                 if (xf_lt(lim, ki)) ki = lim;
                 if (xf_lt(ki, xf_neg(lim))) ki = xf_neg(lim);
                 const xf80 e_new = xf_mul(xf_sub(one, xf_mul(ki, ki)), E);
                 if (xf_lt(e_new, eps)) {
                     stopped = true;
                 } else {
-                    a[i] = ki;
-                    for (int j = 1; j < i; ++j) a[j] = xf_sub(prevA[j], xf_mul(ki, prevA[i - j]));
-                    for (int j = 1; j <= i; ++j) prevA[j] = a[j];
+                    a.set(i, ki);
+                    for (int j = 1; j < i; ++j) a.set(j, xf_sub(prevA.get(j), xf_mul(ki, prevA.get(i - j))));
+                    for (int j = 1; j <= i; ++j) prevA.set(j, a.get(j));
                     E = e_new;
                     achieved = i;
                 }
@@ -325,13 +331,21 @@ LACX_HD void levinson_candidates(const int64_t* r, int max_valid_order, int16_t 
         }
         // candidate order == i: snapshot (used = min(i, achieved))
         if (next_ci < 5 && i == 4 + 2 * next_ci) {
-            if (i <= max_valid_order) {
-                out_used[next_ci] = (uint8_t)achieved;
-                for (int j = 1; j <= achieved; ++j) out_coef[next_ci][j] = xf_to_q15(a[j]);
-            }
+            const bool keep = i <= max_valid_order;
+            put_used(next_ci, keep ? (uint8_t)achieved : (uint8_t)0);
+            for (int j = 0; j <= 12; ++j)
+                put_coef(next_ci, j, (keep && j >= 1 && j <= achieved) ? xf_to_q15(a.get(j)) : (int16_t)0);
             ++next_ci;
         }
     }
+}
+
+LACX_HD void levinson_candidates(const int64_t* r, int max_valid_order, int16_t out_coef[5][13],
+                                 uint8_t out_used[5]) {
+    XfLocalArray R, a, prevA;
+    levinson_candidates_t(
+        [r](int i) { return r[i]; }, max_valid_order, R, a, prevA,
+        [out_coef](int ci, int j, int16_t v) { out_coef[ci][j] = v; }, [out_used](int ci, uint8_t v) { out_used[ci] = v; });
 }
 
 }  // namespace lacx
