@@ -9,6 +9,7 @@ template <int OP>
 __global__ __launch_bounds__(1024) void k_op(uint32_t* out, uint64_t* clk, int iters, uint32_t seed) {
     uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9E3779B9u, c = b + 77u, d = a + 3u;
     uint64_t A = ((uint64_t)a << 20) | b, B = ((uint64_t)c << 12) | d;
+    double fa = 0.0, fb = 1.0, fx = (double)(int)(a & 0xFFFF), fy = (double)(int)(b & 0xFFFF), fz = (double)(int)(c & 0xFF);
     const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -22,10 +23,13 @@ __global__ __launch_bounds__(1024) void k_op(uint32_t* out, uint64_t* clk, int i
             if (OP == 6) { a = a + (uint32_t)__popcll(__ballot((a >> (k & 15)) & 1u)); }   // ballot + popcount
             if (OP == 7) { a = (uint32_t)__clz((int)(a | 1u)) + b; b = b * 3u + 1u; }       // ffbh + mul_lo
             if (OP == 8) { a = (a >> (b & 31)) + c; b = b + 1u; }                            // variable shift
+            if (OP == 9) { A = (uint64_t)((int64_t)(int32_t)a * (int64_t)(int32_t)b) + A; B = (uint64_t)((int64_t)(int32_t)c * (int64_t)(int32_t)d) + B; }  // 2 x v_mad_i64_i32, independent chains
+            if (OP == 10) { fa = __builtin_fma(fx, fy, fa); fb = __builtin_fma(fy, fz, fb); }  // 2 x v_fma_f64
+            if (OP == 11) { a = (uint32_t)((int32_t)a * (int32_t)b) + c; d = (uint32_t)((int32_t)d * (int32_t)b) + c; }  // 2 x v_mul_lo + add (mad_u32)
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + (uint32_t)A + (uint32_t)B;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + (uint32_t)A + (uint32_t)B + (uint32_t)(long long)(fa + fb);
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
@@ -61,5 +65,8 @@ int main() {
     run<6>("ballot+popc (+3)", 5);
     run<7>("ffbh + mul_lo (+3)", 4);
     run<8>("variable shift (+3)", 4);
+    run<9>("2 x v_mad_i64_i32", 2);
+    run<10>("2 x v_fma_f64", 2);
+    run<11>("2 x mul_lo_u32 + add", 4);
     return 0;
 }
