@@ -42,25 +42,30 @@ struct EmitMem {
 
 // plan -> shared memory (thread 0) ---------------------------------------------------------------
 template <class G>
-LACX_HD void emit_load_plan(EmitMem<G>& sh, const ChannelPlan& pl) {
-    sh.ptype = pl.predictor_type;
-    sh.order = pl.order;
-    sh.p = pl.partition_order;
-    sh.parts = pl.partition_order ? (1u << pl.partition_order) : 1u;
-    sh.payload_bytes = pl.payload_bytes;
-    sh.cand = pl.predictor_type == 0 ? pl.order : (pl.predictor_type == 1 ? 5u : 6u);
-    for (int ci = 0; ci < 5; ++ci) {
-        sh.lpc.used[ci] = 0;
-        for (int t = 0; t < 13; ++t) sh.lpc.coef[ci][t] = 0;
+LACX_HD void emit_load_plan(EmitMem<G>& sh, const ChannelPlan& pl, int tid = 0, int nthreads = 1) {
+    // cooperative: every element is written by exactly one of the `nthreads` callers (a single caller does it all)
+    const uint32_t parts = pl.partition_order ? (1u << pl.partition_order) : 1u;
+    const uint32_t order = pl.order;
+    const bool lpc = pl.predictor_type == 2;
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)kMaxParts; i += (uint32_t)nthreads)
+        sh.part_mode_k[i] = (i < parts) ? pl.part_mode_k[i] : (uint8_t)0;
+    for (uint32_t i = (uint32_t)tid; i < 5u * 13u; i += (uint32_t)nthreads) {
+        const uint32_t ci = i / 13u, t = i % 13u;
+        sh.lpc.coef[ci][t] = (lpc && ci == 0u && t >= 1u && t <= order && t <= 12u) ? pl.coef[t - 1u] : (int16_t)0;
     }
-    if (pl.predictor_type == 2) {
-        sh.lpc.used[0] = pl.order;
-        for (int t = 1; t <= pl.order && t <= 12; ++t) sh.lpc.coef[0][t] = pl.coef[t - 1];
+    if (tid == 0) {
+        sh.ptype = pl.predictor_type;
+        sh.order = pl.order;
+        sh.p = pl.partition_order;
+        sh.parts = parts;
+        sh.payload_bytes = pl.payload_bytes;
+        sh.cand = pl.predictor_type == 0 ? pl.order : (pl.predictor_type == 1 ? 5u : 6u);
+        for (int ci = 0; ci < 5; ++ci) sh.lpc.used[ci] = 0;
+        if (lpc) sh.lpc.used[0] = pl.order;
+        sh.lpc.pad = 0;
+        sh.header_bits = 16u + (lpc ? 16u * pl.order : 0u) + 8u + 7u * parts;
+        sh.err = 0;
     }
-    sh.lpc.pad = 0;
-    for (uint32_t i = 0; i < (uint32_t)kMaxParts; ++i) sh.part_mode_k[i] = (i < sh.parts) ? pl.part_mode_k[i] : (uint8_t)0;
-    sh.header_bits = 16u + (pl.predictor_type == 2 ? 16u * pl.order : 0u) + 8u + 7u * sh.parts;
-    sh.err = 0;
 }
 
 // first non-zero index of the chunk (n if none); input of the suffix-min scan
@@ -101,6 +106,66 @@ LACX_HD void put_ones(const BitTile* tile, uint64_t pos, uint32_t q, Or&& or_wor
     if (q) put_bits(tile, pos, (1u << q) - 1u, q, or_word);
 }
 
+// Bit writer of one thread in walk 2.  A thread's tokens form one contiguous bit range of the channel block, so
+// it assembles them in a 64-bit register and writes whole 32-bit words: words strictly inside its range belong
+// to it alone (plain store into the zeroed tile), only its first and its last word can hold a neighbour's bits
+// and are OR-ed.  Words outside the tile are dropped (another pass owns them).
+template <class Or, class St>
+struct TokenSink {
+    uint32_t* words;  // tile storage (copies of the BitTile fields: they must live in registers, not behind a pointer)
+    uint64_t w0;      // first stream word of the tile
+    uint32_t nwords;
+    Or& or_word;
+    St& st_word;
+    uint64_t acc;   // pending bits, left-aligned
+    uint32_t fill;  // number of pending bits (< 32 between calls)
+    uint64_t word;  // stream word index the top 32 bits of acc belong to
+    bool shared;    // that word may also hold bits of the previous thread
+
+    LACX_HD TokenSink(BitTile t, uint64_t pos, Or& o, St& s)
+        : words(t.words), w0(t.bit0 >> 5), nwords(t.nwords), or_word(o), st_word(s), acc(0),
+          fill((uint32_t)(pos & 31u)), word(pos >> 5), shared(true) {}
+    LACX_HD void flush_word(uint32_t w, bool with_or) {
+        if (word < w0 || word >= w0 + nwords) return;
+        if (with_or) {
+            if (w) or_word(&words[word - w0], w);
+        } else {
+            st_word(&words[word - w0], w);
+        }
+    }
+    LACX_HD void put(uint32_t value, uint32_t n) {  // n in 0..32, value < 2^n, MSB first
+        if (n == 0u) return;
+        acc |= (uint64_t)value << (64u - fill - n);
+        fill += n;
+        if (fill >= 32u) {
+            flush_word((uint32_t)(acc >> 32), shared);
+            acc <<= 32;
+            fill -= 32u;
+            ++word;
+            shared = false;
+        }
+    }
+    LACX_HD void put_rice(uint32_t u, uint32_t k) {  // q ones, a zero, k remainder bits
+        uint32_t q = u >> k;
+        const uint32_t rem = k ? (u & ((1u << k) - 1u)) : 0u;
+        if (q + 1u + k <= 32u) {
+            put((((1u << q) - 1u) << (k + 1u)) | rem, q + 1u + k);
+            return;
+        }
+        while (q >= 32u) {
+            put(0xFFFFFFFFu, 32u);
+            q -= 32u;
+        }
+        put((1u << q) - 1u, q);
+        put(rem, k + 1u);
+    }
+    LACX_HD void finish() {  // the last, partial word is shared with the next thread
+        if (fill) flush_word((uint32_t)(acc >> 32), true);
+    }
+};
+
+LACX_HD uint64_t rice_len(uint32_t u, uint32_t k) { return (uint64_t)(u >> k) + 1u + k; }
+
 // Rice code: q ones, a zero, k remainder bits (ref rice.cpp:17-32, block/encoder.cpp:79-87); k <= 31
 template <class Or>
 LACX_HD uint64_t put_rice(const BitTile* tile, uint64_t pos, uint32_t u, uint32_t k, Or&& or_word) {
@@ -116,13 +181,16 @@ LACX_HD uint64_t put_rice(const BitTile* tile, uint64_t pos, uint32_t u, uint32_
 // One walk over the thread's chunk.  PASS 1 (tile == nullptr): computes kin per sample (stored in
 // sh.xp.o.kin) and returns the thread's token bits.  PASS 2: writes the tokens starting at bit `pos`.
 // The walk mirrors phase_b (stateful, p == 0) / partition_pass (stateless, p > 0).
-template <class G, bool NARROW, class Or>
-LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile, uint64_t pos, Or&& or_word) {
+template <class G, bool NARROW, bool PASS1, class Or, class St>
+LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile_in, uint64_t pos, Or&& or_word,
+                             St&& st_word) {
     if (th.cnt <= 0) return 0;
+    const BitTile* tile = PASS1 ? nullptr : tile_in;
+    TokenSink<Or, St> sink(tile ? *tile : BitTile{nullptr, 0, 0}, pos, or_word, st_word);
     const int t = th.tid;
     const uint32_t n = th.n;
     const uint32_t p = sh.p, parts = sh.parts;
-    const bool pass1 = tile == nullptr;
+    constexpr bool pass1 = PASS1;
     const uint32_t base = p ? (n >> p) : n;
     uint32_t part = p ? ((uint32_t)th.a / base) : 0u;
     if (part >= parts) part = parts - 1u;
@@ -179,19 +247,22 @@ LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* t
         }
         // ---- token ----
         uint64_t len = 0;
-        const uint64_t at = pos + bits;
         if (mode == 0u || mode == 3u) {
-            len = put_rice(tile, at, u, kin, or_word);
+            if (tile) sink.put_rice(u, kin);
+            len = rice_len(u, kin);
         } else if (mode == 2u) {  // bin (ref block/encoder.cpp:609-667)
             if (u == 0u) {
-                if (tile) put_bits(tile, at, 0u, 2u, or_word);
+                if (tile) sink.put(0u, 2u);
                 len = 2;
             } else if (u <= 4u) {  // |v| = 1 -> tag 01, |v| = 2 -> tag 10, then the sign (u odd <=> negative)
-                if (tile) put_bits(tile, at, ((u <= 2u ? 1u : 2u) << 1) | (u & 1u), 3u, or_word);
+                if (tile) sink.put(((u <= 2u ? 1u : 2u) << 1) | (u & 1u), 3u);
                 len = 3;
             } else {
-                if (tile) put_bits(tile, at, 3u, 2u, or_word);
-                len = 2u + put_rice(tile, at + 2u, u, kin, or_word);
+                if (tile) {
+                    sink.put(3u, 2u);
+                    sink.put_rice(u, kin);
+                }
+                len = 2u + rice_len(u, kin);
             }
         } else {  // zero-run (ref block/encoder.cpp:669-771)
             const bool z = (u == 0u);
@@ -203,13 +274,16 @@ LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* t
                 const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
                 if (u > esc) {
                     if (tile) {
-                        put_bits(tile, at, 2u, 2u, or_word);
-                        put_bits(tile, at + 2u, u, 32u, or_word);
+                        sink.put(2u, 2u);
+                        sink.put(u, 32u);
                     }
                     len = 34;
                 } else {
-                    if (tile) put_bits(tile, at, 0u, 2u, or_word);
-                    len = 2u + put_rice(tile, at + 2u, u, kin, or_word);
+                    if (tile) {
+                        sink.put(0u, 2u);
+                        sink.put_rice(u, kin);
+                    }
+                    len = 2u + rice_len(u, kin);
                 }
             } else if (f == 1) {  // first sample of a run of >= 4 zeros: one token for the whole run
                 // run length: up to the next non-zero sample or the end of the partition
@@ -222,8 +296,11 @@ LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* t
                 }
                 if (nx == n) nx = (uint32_t)sh.tabNX[t];
                 const uint32_t run = (nx < e ? nx : e) - j;
-                if (tile) put_bits(tile, at, 1u, 2u, or_word);
-                len = 2u + put_rice(tile, at + 2u, run - 4u, 2u, or_word);
+                if (tile) {
+                    sink.put(1u, 2u);
+                    sink.put_rice(run - 4u, 2u);
+                }
+                len = 2u + rice_len(run - 4u, 2u);
             }
         }
         if (mode != 1u) {  // keep the run counter coherent when modes change between partitions
@@ -249,7 +326,16 @@ LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* t
         x2 = x3;
         x3 = peek_u<G>(sh, j + 4u, n);
     }
+    if (tile) sink.finish();
     return bits;
+}
+
+// PASS 1 when tile == nullptr, PASS 2 otherwise (the second pass does not depend on the prefix-sum width)
+template <class G, bool NARROW, class Or, class St>
+LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile, uint64_t pos, Or&& or_word,
+                           St&& st_word) {
+    if (tile == nullptr) return emit_walk_t<G, NARROW, true>(th, sh, nullptr, pos, or_word, st_word);
+    return emit_walk_t<G, true, false>(th, sh, tile, pos, or_word, st_word);
 }
 
 // Header fields (ref block/encoder.cpp:773-795), spread over the first threads.

@@ -33,6 +33,18 @@ __device__ unsigned long long g_stamp_acc[32];
 #else
 #define STAMP(k) do { } while (0)
 #endif
+// -DLACX_STAMPS=2: the same for k_emit (its stamps land in the same accumulator; k_analyze's still run but the
+// reader is expected to launch the emit only after a reset)
+#if defined(LACX_STAMPS) && LACX_STAMPS == 2
+#define ESTAMP(k)                                                       \
+    do {                                                                \
+        const unsigned long long _now = __builtin_amdgcn_s_memtime();   \
+        estamp_acc[k] += _now - estamp_prev;                            \
+        estamp_prev = _now;                                             \
+    } while (0)
+#else
+#define ESTAMP(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
@@ -732,7 +744,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     }
     if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, plan_out);
     STAMP(21);
-#ifdef LACX_STAMPS
+#if defined(LACX_STAMPS) && LACX_STAMPS == 1
     if ((tid & 63) == 0 && G::T == 1024) {
         stamp_acc[22] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
         for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
@@ -922,16 +934,23 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     }
     if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
 
+#if defined(LACX_STAMPS) && LACX_STAMPS == 2
+    unsigned long long estamp_acc[24];
+    for (int k = 0; k < 24; ++k) estamp_acc[k] = 0;
+    unsigned long long estamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long estamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     Thread<G> th;
     thread_init(th, n, tid);
     stage_samples(th, sh, slot_src(prm, L, R, kind), (int64_t)blk * kMaxBlock);
-    if (tid == 0) {
-        emit_load_plan(sh, *plan);
-        if (!plan->valid) sh.err = 1;
-    }
+    ESTAMP(0);
+    emit_load_plan(sh, *plan, tid, G::T);
+    if (tid == 0 && !plan->valid) sh.err = 1;
     __syncthreads();
+    ESTAMP(1);
     phase_r(th, sh, (int)sh.cand);
     emit_first_nonzero(th, sh);
+    ESTAMP(2);
     ScanRegs<G> sr;
     scan_pz_part1<G>(sh, tid, sr);
     const int32_t nxinc = scan_nx_part1(sh, tid, s_wx);
@@ -939,6 +958,7 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     scan_pz_part2<G>(sh, tid, sr);
     scan_nx_part2(sh, tid, nxinc, s_wx, (int32_t)n);
     __syncthreads();
+    ESTAMP(3);
     const bool narrow = sh.tabP[G::T] < (1ull << 31);
     const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
     if (adaptive0) {
@@ -953,11 +973,15 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
         scan_f_part2<G>(sh, tid, finc, fown);
         __syncthreads();
     }
+    ESTAMP(4);
     auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
+    auto stw = [](uint32_t* w, uint32_t v) { *w = v; };
     // walk 1: Rice parameter per sample + token bits of the chunk
-    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw)
-                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw);
+    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw, stw)
+                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw, stw);
+    ESTAMP(5);
     __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
+    ESTAMP(6);
     sh.tabP[tid] = mybits;
     {
         // sum scan of the bit counts (tabP only)
@@ -981,22 +1005,26 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
     if (nbytes != sh.payload_bytes || sh.err) return;  // uniform: never write outside the planned byte range
     const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
+    ESTAMP(7);
 
     // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
     for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
         for (int i = tid; i < kEmitTileWords; i += G::T) sh.xp.o.obits[i] = 0;
         __syncthreads();
+        ESTAMP(8);
         BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
         if (bit0 == 0) emit_header(th, sh, &tile, orw);
         const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
         if (mypos < tile_end && mypos + mybits > bit0) {
             if (narrow) {
-                emit_walk<G, true>(th, sh, &tile, mypos, orw);
+                emit_walk<G, true>(th, sh, &tile, mypos, orw, stw);
             } else {
-                emit_walk<G, false>(th, sh, &tile, mypos, orw);
+                emit_walk<G, false>(th, sh, &tile, mypos, orw, stw);
             }
         }
+        ESTAMP(9);
         __syncthreads();
+        ESTAMP(10);
         const unsigned long long byte0 = bit0 >> 3;
         const unsigned long long left = nbytes - byte0;
         const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
@@ -1032,8 +1060,17 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
             const uint32_t t0 = head + (nvec << 4);
             if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
         }
+        ESTAMP(11);
         __syncthreads();
+        ESTAMP(12);
     }
+#if defined(LACX_STAMPS) && LACX_STAMPS == 2
+    if ((tid & 63) == 0) {
+        estamp_acc[22] = __builtin_amdgcn_s_memrealtime() - estamp_rt0;
+        for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], estamp_acc[k]);
+        atomicAdd(&g_stamp_acc[24], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 // definitions.  This lets the CPU test-suite check the data-parallel reformulation against the oracle
 // without a GPU.  It is not part of the product and is not a fallback: nothing under
 // lossless-audio-codec_amd/ links or loads it.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -229,10 +230,22 @@ int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t*
             run += v;
         }
     }
-    auto orw = [](uint32_t* w, uint32_t v) { *w |= v; };
+    // ownership check of the token writer: a plainly stored word must be untouched before and never OR-ed after
+    std::vector<uint8_t> owned(kEmitTileWords, 0);
+    int ownership_errors = 0;
+    uint32_t* tile_base = sh.xp.o.obits;
+    auto orw = [&](uint32_t* w, uint32_t v) {
+        if (owned[w - tile_base]) ++ownership_errors;
+        *w |= v;
+    };
+    auto stw = [&](uint32_t* w, uint32_t v) {
+        if (*w != 0 || owned[w - tile_base]) ++ownership_errors;
+        owned[w - tile_base] = 1;
+        *w = v;
+    };
     std::vector<uint64_t> bits(G::T), off(G::T);
     for (int t = 0; t < G::T; ++t)
-        bits[t] = narrow ? emit_walk<G, true>(th[t], sh, nullptr, 0, orw) : emit_walk<G, false>(th[t], sh, nullptr, 0, orw);
+        bits[t] = narrow ? emit_walk<G, true>(th[t], sh, nullptr, 0, orw, stw) : emit_walk<G, false>(th[t], sh, nullptr, 0, orw, stw);
     uint64_t total = sh.header_bits;
     for (int t = 0; t < G::T; ++t) {
         off[t] = total;
@@ -245,10 +258,11 @@ int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t*
     if (rc >= 0) {
         for (uint64_t bit0 = 0; bit0 < bytes * 8; bit0 += (uint64_t)kEmitTileWords * 32) {
             for (int i = 0; i < kEmitTileWords; ++i) sh.xp.o.obits[i] = 0;
+            std::fill(owned.begin(), owned.end(), 0);
             BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
             for (int t = 0; t < G::T; ++t) {
                 emit_header(th[t], sh, &tile, orw);
-                if (narrow) emit_walk<G, true>(th[t], sh, &tile, off[t], orw); else emit_walk<G, false>(th[t], sh, &tile, off[t], orw);
+                if (narrow) emit_walk<G, true>(th[t], sh, &tile, off[t], orw, stw); else emit_walk<G, false>(th[t], sh, &tile, off[t], orw, stw);
             }
             const uint64_t byte0 = bit0 / 8;
             for (uint64_t b = byte0; b < bytes && b < byte0 + (uint64_t)kEmitTileWords * 4; ++b) {
@@ -257,6 +271,7 @@ int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t*
             }
         }
     }
+    if (ownership_errors) rc = -4;
     delete shp;
     return rc;
 }
