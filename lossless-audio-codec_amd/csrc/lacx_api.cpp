@@ -99,7 +99,23 @@ int ensure_device(lacx_encoder* e) {
     if (dev >= count) return fail(e, LACX_E_DEVICE, "HIP device ordinal out of range");
     HIP_TRY(e, hipSetDevice(dev), "hipSetDevice");
     e->device = dev;
-    for (auto& s : e->stream) HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    {
+        // Pipeline chunk c runs on stream c: earlier chunks get the higher priority so that they finish their
+        // analysis first and their emit (PCIe-bound) runs under the later chunks' analysis.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool prio = std::getenv("LACX_NO_STREAM_PRIORITY") == nullptr && greatest < least;
+        int i = 0;
+        for (auto& s : e->stream) {
+            if (prio) {
+                const int p = std::min(greatest + i, least);
+                HIP_TRY(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p), "hipStreamCreate");
+            } else {
+                HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+            }
+            ++i;
+        }
+    }
     for (auto& row : e->ev)
         for (auto& ev : row) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
     for (auto& ev : e->done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
@@ -238,13 +254,21 @@ struct Chunk {
 // measured best.
 std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false) {
     uint32_t nchunks = nb / kMinChunkBlocks;
-    nchunks = std::max(1u, std::min(nchunks, device_emit ? 2u : 8u));
+    nchunks = std::max(1u, std::min(nchunks, device_emit ? 3u : 8u));
+    bool forced = false;
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
         const unsigned long v = std::strtoul(env, nullptr, 0);
-        if (v >= 1 && v <= (unsigned long)kMaxChunks) nchunks = std::min<uint32_t>((uint32_t)v, nb);
+        if (v >= 1 && v <= (unsigned long)kMaxChunks) {
+            nchunks = std::min<uint32_t>((uint32_t)v, nb);
+            forced = true;
+        }
     }
     std::vector<Chunk> out;
-    if (const char* env = std::getenv("LACX_PIPE_SPLIT")) {  // tuning knob: relative chunk sizes, e.g. "5,3,1"
+    const char* split_env = std::getenv("LACX_PIPE_SPLIT");  // tuning knob: relative chunk sizes, e.g. "5,3,1"
+    // Device emit: three chunks on three streams of falling priority, the last one a little smaller -- its
+    // emit is the only one whose PCIe writes are not hidden under another chunk's analysis (measured best).
+    if (!split_env && !forced && device_emit && nchunks == 3u) split_env = "5,5,4";
+    if (const char* env = split_env) {
         std::vector<double> w;
         double sum = 0;
         for (const char* p = env; *p && w.size() < (size_t)kMaxChunks;) {
