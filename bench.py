@@ -158,7 +158,8 @@ def main():
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench itself)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
-        if args.seconds == SECONDS and world == 1 and not args.host_emit and abs(n_launch - 2.0) < 1e-9:
+        if (args.seconds == SECONDS and world == 1 and not args.host_emit
+                and abs(n_launch - float(tj.get("launches_per_step", 2))) < 1e-9):
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
