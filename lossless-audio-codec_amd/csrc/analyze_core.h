@@ -349,19 +349,23 @@ LACX_HD bool stage_span(const SlotSrc& s, int64_t first, int32_t* v) {
     return true;
 }
 
+// The CH samples [first, first + CH) of a slot into v[]: one span fetch when all of them exist (cnt == CH) and
+// the span is aligned, else sample by sample with the index clamped to `last` (callers mask what lies beyond).
+template <int CH>
+LACX_HD void load_chunk(const SlotSrc& src, int64_t first, int cnt, int64_t last, int32_t* v) {
+    if (cnt == CH && stage_span<CH>(src, first, v)) return;
+    // per-sample path: all loads are issued before the first use
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int64_t idx = first + i;
+        v[i] = slot_fetch(src, idx < last ? idx : last);
+    }
+}
+
 template <class G, class M>
 LACX_HD void stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
     int32_t v[G::CH];
-    if (!(th.cnt == G::CH && stage_span<G::CH>(src, start + th.a, v))) {
-        // per-sample path: all loads are issued before the first use (indices clamped into the slot,
-        // values masked after)
-        const int64_t last = start + (int64_t)th.n - 1;
-#pragma unroll
-        for (int i = 0; i < G::CH; ++i) {
-            const int64_t idx = start + th.a + i;
-            v[i] = slot_fetch(src, idx < last ? idx : last);
-        }
-    }
+    load_chunk<G::CH>(src, start + th.a, th.cnt, start + (int64_t)th.n - 1, v);
     int32_t* col = &sh.xp.x[th.tid];
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) col[i * G::T] = (i < th.cnt) ? v[i] : 0;

@@ -269,7 +269,8 @@ __device__ __forceinline__ uint64_t approx_rice_bits(uint64_t sum, uint64_t coun
 }
 
 constexpr int kIngestThreads = 256;
-constexpr int kIngestTile = 1024;
+constexpr int kIngestTile = 4096;
+static_assert(kIngestThreads == kProbe, "one probe sample per thread");
 
 __device__ __forceinline__ bool slot_channel_used(const AnalyzeParams& prm, int ch) {
     if (prm.channels == 1) return ch == 0;
@@ -312,7 +313,13 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
                                                            unsigned long long* __restrict__ sums,
                                                            uint32_t* __restrict__ badidx,
                                                            int64_t* __restrict__ acorr) {
-    __shared__ int32_t s_tile[12 + kIngestTile];
+    // One tile = 4096 samples = 16 consecutive samples per thread, kept in LDS as 4-sample groups in four planes:
+    // group g of the tile (samples 4g..4g+3) sits in plane g % 4 at index g / 4 (+1: index 0 of a plane is the
+    // group carried over from the previous tile).  Thread t writes its groups 4t..4t+3 -- one 16-byte store per
+    // plane, consecutive lanes at consecutive slots -- and, for the 12 samples of history its first group needs,
+    // reads groups 4t-3..4t-1 = planes 1..3 at index t-1: every access is conflict-free.
+    __shared__ int4 s_plane[4][kIngestThreads + 1];
+    __shared__ int32_t s_win[12 + kProbe];
     __shared__ unsigned long long s_ac[13];
     __shared__ unsigned long long s_sum[3];
     __shared__ unsigned int s_bad;
@@ -332,68 +339,79 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     const int32_t hi = prm.bit_depth == 16 ? 32767 : 0x7FFFFF;
     if (tid < 3) s_sum[tid] = 0;
     if (tid == 0) s_bad = 0xFFFFFFFFu;
-    if (tid < 12) s_tile[tid] = 0;  // history before the block start counts as absent (lags start at n = k)
+    // history before the block start counts as absent (lags start at n = k): the carried groups start as zero
+    if (tid < 4) s_plane[tid][0] = make_int4(0, 0, 0, 0);
     __syncthreads();
 
+    constexpr int kPerThread = kIngestTile / kIngestThreads;
+    static_assert(kPerThread == 16, "four 4-sample groups per thread and tile");
     int64_t acc[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) acc[k] = 0;
     uint64_t sraw = 0, sdif = 0, sant = 0;
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t base = 0; base < nb; base += kIngestTile) {
-        // stage samples [base, base + tile) behind 12 samples of history
+        // the thread's 16 samples: one span fetch (16-byte loads) in every layout
+        const uint32_t first = base + 16u * (uint32_t)tid;
+        const int rem = (int)nb - (int)first;
+        const int cnt = rem < 0 ? 0 : (rem > 16 ? 16 : rem);
+        int32_t w[28];  // w[12 + i] = sample first + i, w[0..11] = the 12 samples before
+        load_chunk<16>(src, bstart + first, cnt, bstart + (int64_t)nb - 1, w + 12);
 #pragma unroll
-        for (int q = 0; q < kIngestTile / kIngestThreads; ++q) {
-            const uint32_t i = base + (uint32_t)(q * kIngestThreads + tid);
-            int32_t v = 0;
-            if (i < nb) {
-                v = slot_fetch(src, bstart + i);
-                if (validate && (v < lo || v > hi)) bad = bad < i ? bad : i;
+        for (int i = 0; i < 16; ++i) {
+            if (i >= cnt) w[12 + i] = 0;  // past the block end: adds nothing to any lag
+            else if (validate && (w[12 + i] < lo || w[12 + i] > hi)) bad = bad < first + (uint32_t)i ? bad : first + (uint32_t)i;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            s_plane[c][tid + 1] = make_int4(w[12 + 4 * c], w[13 + 4 * c], w[14 + 4 * c], w[15 + 4 * c]);
+        __syncthreads();
+        int4 carry = make_int4(0, 0, 0, 0);
+        if (tid >= 1 && tid <= 3) carry = s_plane[tid][kIngestThreads];  // last groups of the tile, for the next one
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const int4 h = s_plane[c][tid];  // group 4(t-1)+c
+            w[4 * (c - 1)] = h.x;
+            w[4 * (c - 1) + 1] = h.y;
+            w[4 * (c - 1) + 2] = h.z;
+            w[4 * (c - 1) + 3] = h.w;
+        }
+        if (used) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int k = 0; k < 13; ++k) acc[k] += (int64_t)w[12 + i] * (int64_t)w[12 + i - k];
             }
-            s_tile[12 + q * kIngestThreads + tid] = v;
+            if (est) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i < cnt) {
+                        const int64_t x0 = w[12 + i], prev = w[11 + i];
+                        const uint64_t raw = zz64(x0);
+                        const bool head = (first + (uint32_t)i) == 0u;
+                        sraw += raw;
+                        sdif += head ? raw : zz64(x0 - prev);
+                        sant += head ? raw : zz64(x0 + prev);
+                    }
+                }
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kIngestTile / kIngestThreads; ++q) {
-            const int li = 12 + q * kIngestThreads + tid;
-            const uint32_t i = base + (uint32_t)(q * kIngestThreads + tid);
-            if (used && i < nb) {
-                const int64_t x0 = s_tile[li];
-#pragma unroll
-                for (int k = 0; k < 13; ++k) {
-                    // lag k pairs x[i] with x[i-k]; samples before the block start are excluded (n >= k)
-                    const int64_t xk = (i >= (uint32_t)k) ? (int64_t)s_tile[li - k] : 0;
-                    acc[k] += x0 * xk;
-                }
-                if (est) {
-                    const uint64_t raw = zz64(x0);
-                    const int64_t prev = s_tile[li - 1];
-                    sraw += raw;
-                    sdif += (i == 0) ? raw : zz64(x0 - prev);
-                    sant += (i == 0) ? raw : zz64(x0 + prev);
-                }
-            }
-        }
-        __syncthreads();
-        // carry the last 12 samples of the tile over as history of the next one
-        if (tid < 12) s_tile[tid] = s_tile[kIngestTile + tid];
-        __syncthreads();
+        if (tid >= 1 && tid <= 3) s_plane[tid][0] = carry;
+        // (the next tile's stores do not touch index 0; its barrier orders this store before thread 0's read)
     }
     if (used) reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + ch) * 13, tid);
 
-    // probe windows (per-block stereo, blocks above the full-comparison limit only)
+    // probe windows (per-block stereo, blocks above the full-comparison limit only): 256 samples each, lags
+    // inside the window only
     if (est && nb > (uint32_t)kFullCompareLimit) {
+        if (tid < 12) s_win[tid] = 0;
         for (int w = 1; w <= 3; ++w) {
             const SlotGeom g = slot_geom(prm, blk, w * 4 + ch);
+            s_win[12 + tid] = slot_fetch(src, g.start + tid);  // kIngestThreads == kProbe
+            __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 13; ++k) acc[k] = 0;
-            if (tid < kProbe) {
-                const int64_t x0 = slot_fetch(src, g.start + tid);
-#pragma unroll
-                for (int k = 0; k < 13; ++k) {
-                    if (tid >= k) acc[k] += x0 * (int64_t)slot_fetch(src, g.start + tid - k);
-                }
-            }
+            for (int k = 0; k < 13; ++k) acc[k] = (int64_t)s_win[12 + tid] * (int64_t)s_win[12 + tid - k];
             reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + w * 4 + ch) * 13, tid);
         }
     }
