@@ -59,16 +59,72 @@ __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int d) {
     const uint32_t hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), d, 64);
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {  // result valid in lane 0
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+// Wave-wide inclusive scans and reductions on the DPP network (gfx9 row_shr / row_bcast), which is part of the
+// VALU pipeline: six full-rate moves per scan instead of six trips through the LDS crossbar (ds_bpermute).
+//   row_shr:n       lane i of a 16-lane row reads lane i-n of the same row
+//   row_bcast:15/31 lane 15 (31) is broadcast to the following row (two rows)
+// Lanes without a source keep `identity`.  Every lane must be active.
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_mov64(uint64_t v) {  // identity 0
+    const uint32_t lo = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)v);
+    const uint32_t hi = dpp_mov<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {  // inclusive prefix sum over the 64 lanes
+    v += dpp_mov<kDppRowShr1, 0xF>(0u, v);
+    v += dpp_mov<kDppRowShr2, 0xF>(0u, v);
+    v += dpp_mov<kDppRowShr4, 0xF>(0u, v);
+    v += dpp_mov<kDppRowShr8, 0xF>(0u, v);
+    v += dpp_mov<kDppRowBcast15, 0xA>(0u, v);
+    v += dpp_mov<kDppRowBcast31, 0xC>(0u, v);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_down((int)v, d, 64);
+__device__ __forceinline__ uint64_t wave_scan_add_u64(uint64_t v) {
+    v += dpp_mov64<kDppRowShr1, 0xF>(v);
+    v += dpp_mov64<kDppRowShr2, 0xF>(v);
+    v += dpp_mov64<kDppRowShr4, 0xF>(v);
+    v += dpp_mov64<kDppRowShr8, 0xF>(v);
+    v += dpp_mov64<kDppRowBcast15, 0xA>(v);
+    v += dpp_mov64<kDppRowBcast31, 0xC>(v);
     return v;
 }
+__device__ __forceinline__ int32_t wave_scan_max_i32(int32_t v) {  // inclusive prefix max; identity INT32_MIN
+    constexpr uint32_t kMin = 0x80000000u;
+    auto mx = [](int32_t a, uint32_t b) { return a > (int32_t)b ? a : (int32_t)b; };
+    v = mx(v, dpp_mov<kDppRowShr1, 0xF>(kMin, (uint32_t)v));
+    v = mx(v, dpp_mov<kDppRowShr2, 0xF>(kMin, (uint32_t)v));
+    v = mx(v, dpp_mov<kDppRowShr4, 0xF>(kMin, (uint32_t)v));
+    v = mx(v, dpp_mov<kDppRowShr8, 0xF>(kMin, (uint32_t)v));
+    v = mx(v, dpp_mov<kDppRowBcast15, 0xA>(kMin, (uint32_t)v));
+    v = mx(v, dpp_mov<kDppRowBcast31, 0xC>(kMin, (uint32_t)v));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_or_u32(uint32_t v) {
+    v |= dpp_mov<kDppRowShr1, 0xF>(0u, v);
+    v |= dpp_mov<kDppRowShr2, 0xF>(0u, v);
+    v |= dpp_mov<kDppRowShr4, 0xF>(0u, v);
+    v |= dpp_mov<kDppRowShr8, 0xF>(0u, v);
+    v |= dpp_mov<kDppRowBcast15, 0xA>(0u, v);
+    v |= dpp_mov<kDppRowBcast31, 0xC>(0u, v);
+    return v;
+}
+// value of lane 63 in every lane (a scalar register)
+__device__ __forceinline__ uint32_t wave_last_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint64_t wave_last_u64(uint64_t v) {
+    return ((uint64_t)wave_last_u32((uint32_t)(v >> 32)) << 32) | wave_last_u32((uint32_t)v);
+}
+// reductions: the total, in every lane
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return wave_last_u64(wave_scan_add_u64(v)); }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_scan_add_u32(v)); }
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) { return wave_last_u32(wave_scan_or_u32(v)); }
 
 // Block exclusive scans of the per-thread values the phases left in tabP/tabNZ (sum / max).
 // part 1 before the barrier, part 2 after it.
@@ -83,17 +139,8 @@ __device__ __forceinline__ void scan_pz_part1(M& sh, int tid, ScanRegs<G>& r) {
     const int lane = tid & 63, wave = tid >> 6;
     r.v = sh.tabP[tid];
     r.z = sh.tabNZ[tid];
-    uint64_t inc = r.v;
-    int32_t zinc = r.z;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t o = shfl_up_u64(inc, d);
-        const int32_t oz = __shfl_up(zinc, d, 64);
-        if (lane >= d) {
-            inc += o;
-            zinc = oz > zinc ? oz : zinc;
-        }
-    }
+    const uint64_t inc = wave_scan_add_u64(r.v);
+    const int32_t zinc = wave_scan_max_i32(r.z);
     r.inc = inc;
     r.zinc = zinc;
     if (lane == 63) {
@@ -126,12 +173,7 @@ template <class G, class M>
 __device__ __forceinline__ uint32_t scan_f_part1(M& sh, int tid, uint32_t& own) {
     const int lane = tid & 63, wave = tid >> 6;
     own = sh.tabF[tid];
-    uint32_t inc = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
-    }
+    const uint32_t inc = wave_scan_add_u32(own);
     if (lane == 63) sh.wtotF[wave] = inc;
     return inc;
 }
@@ -155,9 +197,7 @@ __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t*
     uint32_t any = 0;
 #pragma unroll
     for (int l = 0; l < G::LV; ++l) any |= th.cs[l];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) any |= (uint32_t)__shfl_xor((int)any, d, 64);
-    const int nplanes = 32 - __clz((int)__builtin_amdgcn_readfirstlane((int)any));  // uniform, 0..30
+    const int nplanes = 32 - __clz((int)wave_or_u32(any));  // uniform, 0..30
     // lanes of wave 0 whose chunk lies inside the first 256 samples
     const uint64_t m256 = (G::W256 >= 64) ? ~0ull : ((1ull << (G::W256 & 63)) - 1ull);
     uint32_t mine = 0, mine256 = 0;
@@ -186,14 +226,9 @@ __device__ __forceinline__ void wave_exclusive_scan_u32(uint32_t* arr, int len, 
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;
         const uint32_t v = (i < len) ? arr[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-            if (lane >= d) inc += o;
-        }
+        const uint32_t inc = wave_scan_add_u32(v);
         if (i < len) arr[i] = carry + inc - v;
-        carry += (uint32_t)__shfl((int)inc, 63, 64);
+        carry += wave_last_u32(inc);
     }
 }
 
@@ -599,12 +634,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         STAMP(3);
         {
             // block sums for the pruning bound
-            uint32_t g = th.lb_g, a = th.lb_aux;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                g += (uint32_t)__shfl_down((int)g, d, 64);
-                a += (uint32_t)__shfl_down((int)a, d, 64);
-            }
+            const uint32_t g = wave_sum_u32(th.lb_g), a = wave_sum_u32(th.lb_aux);
             if ((tid & 63) == 0) {
                 atomicAdd(&sh.lbacc[cand][0], g);
                 atomicAdd(&sh.lbacc[cand][1], a);
@@ -878,12 +908,7 @@ __global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const Block
         table[2 * b + 1] = bytes;
         sum += bytes;
     }
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = shfl_up_u64(inc, d);
-        if (lane >= d) inc += o;
-    }
+    const unsigned long long inc = wave_scan_add_u64(sum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
     unsigned long long base = base_ptr ? *base_ptr : 0ull;  // bytes of the chunks before this one
@@ -1004,12 +1029,7 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     {
         // sum scan of the bit counts (tabP only)
         const int lane = tid & 63, wave = tid >> 6;
-        unsigned long long inc = mybits;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = shfl_up_u64(inc, d);
-            if (lane >= d) inc += o;
-        }
+        const unsigned long long inc = wave_scan_add_u64(mybits);
         if (lane == 63) sh.wtotP[wave] = inc;
         __syncthreads();
         unsigned long long base = 0;
