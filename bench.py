@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- encode throughput of the MI355X LAC block-encode path (BASELINE.json metric).
 
-A "step" is one whole-job encode of the rank's shard: device analysis (all kernels) of PCM already
-resident in HBM -> plan records D2H -> host bit emit -> shard payload + block table; for N > 1 the
-ranks then all_gather their block-size tables over RCCL (the path's only exchange step) so every rank
-knows its byte offset in the final .lac.  Workload at N=1 = BASELINE configs[1]: 10 min synthetic
-stereo 16-bit 48 kHz, per-block auto MS/LR, LPC search, default 16384-frame blocks; with N ranks the
-stream is N x 10 min and rank r takes the r-th contiguous block range (weak scaling).
+A "step" is one whole-job encode of the rank's shard with the PCM already resident in HBM in its source
+layout (interleaved int16, the WAV data chunk): ingest + Levinson + probe/whole-block analysis kernels,
+device-side bit emit straight into pinned host memory, block table D2H -> shard payload + block table on the
+host.  For N > 1 the ranks then all_gather (payload bytes, block count) over RCCL -- the path's only exchange
+step -- so every rank knows its byte offset in the final .lac.  Workload at N=1 = BASELINE configs[1]: 10 min
+synthetic stereo 16-bit 48 kHz, per-block auto MS/LR, LPC search, default 16384-frame blocks; with N ranks
+the stream is N x 10 min and rank r takes the r-th contiguous block range (weak scaling).
 
 Prints ONE JSON line on rank 0.
 """
