@@ -117,7 +117,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    full_ms, analysis_ms, emit_ms, probe_ms, ingest_ms, launches, api_ms = [], [], [], [], [], [], []
+    full_ms, analysis_ms, emit_ms, probe_ms, ingest_ms, launches, api_ms, exec_ms = [], [], [], [], [], [], [], []
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
@@ -130,6 +130,7 @@ def main():
         ingest_ms.append(t.ingest_ms)
         launches.append(max(1, t.full_launches))
         api_ms.append(t.total_ms)
+        exec_ms.append(t.full_exec_ms)
     sync()
     elapsed = time.perf_counter() - t0
     tm = enc.timing()
@@ -151,8 +152,14 @@ def main():
     # algorithmic bytes per launch = samples it analyses x bit_depth/8 (each PCM byte once)
     # + the plan records it writes (296 B per analysed channel block).
     # The pipeline launches the kernel once per chunk: duration and bytes are per launch (averages).
+    # Two live measurements of a launch: (a) hipEvents around it on its stream -- the contract's figure, used for
+    # `achieved`; with the pipeline's three chunks on three prioritised streams it includes the time a launch
+    # queues behind / shares the chip with the other chunks' kernels -- and (b) the span between the device-clock
+    # stamps of its first workgroup's start and last workgroup's end, which is what rocprofv3's kernel trace
+    # measures (profiles/*_kernel_stats_bench.csv).
     n_launch = float(np.mean(launches))
     kernel_s = float(np.mean(full_ms)) / 1e3 / n_launch
+    exec_s = float(np.mean(exec_ms)) / 1e3 / n_launch
     algo_bytes = (frames * 2 * (BIT_DEPTH // 8) + tm.full_slots * 296) / n_launch
     achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     traffic = None
@@ -173,6 +180,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 6),
         "traffic": traffic,
         "kernel_ms": round(kernel_s * 1e3, 4),
+        "kernel_exec_ms": round(exec_s * 1e3, 4) if exec_s > 0 else None,
         "launches_per_step": n_launch,
         "algorithmic_bytes": int(algo_bytes),
         "note": "integer-VALU-bound search (~1e3 lane-ops/sample): HBM fraction is structurally small; "

@@ -92,6 +92,8 @@ typedef struct lacx_timing {
     uint64_t probe_slots;
     uint32_t full_launches; /* launches of the dominant kernel in the call (one per pipeline chunk) */
     uint32_t reserved;
+    double full_exec_ms;    /* device emit pipeline: k_analyze<16,1024> execution spans (first workgroup start to last
+                               workgroup end, device clock), summed over its launches -- full_ms minus queueing */
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);

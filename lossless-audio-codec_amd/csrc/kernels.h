@@ -19,6 +19,10 @@ struct DeviceWorkspace {
     unsigned long long* block_off = nullptr;  // [num_blocks + 1] payload byte offsets (device emit)
     uint32_t* table = nullptr;      // [num_blocks][2] (frames, bytes) block table entries
     uint32_t* err_flag = nullptr;   // device emit consistency flag
+    // device clock (100 MHz) at which the first / last workgroup of the whole-block analysis kernel started /
+    // ended: its execution span without the time it queued behind other streams (null = not recorded)
+    unsigned long long* t_first = nullptr;
+    unsigned long long* t_last = nullptr;
 };
 
 // Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).

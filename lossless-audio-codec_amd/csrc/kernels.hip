@@ -806,9 +806,12 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
                                                   AnalyzeParams prm, int probe_class, uint32_t blk_offset,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
-                                                  ChannelPlan* __restrict__ plans) {
+                                                  ChannelPlan* __restrict__ plans,
+                                                  unsigned long long* __restrict__ t_first,
+                                                  unsigned long long* __restrict__ t_last) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x;
+    if (t_first && tid == 0) atomicMin(t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
     // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
     // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
@@ -842,6 +845,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     const SlotSrc src = slot_src(prm, L, R, slot & 3);
 
     analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid);
+    if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1195,20 +1199,22 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     if (autost) {
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
-                           d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans);
+                           d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr,
+                           (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     const uint32_t per = prm.channels == 2 ? 2u : 1u;
     hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * per), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left,
-                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans);
+                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last);
     // Only a final block of <= 4096 frames can need all four channels (full LR-vs-MS comparison,
     // ref lac/encoder.cpp:336-340): its 3rd and 4th slots go in a two-workgroup launch.
     const uint64_t last_frames = prm.frames - (uint64_t)(nb - 1) * kMaxBlock;
     if (autost && last_frames <= (uint64_t)kFullCompareLimit) {
         hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left, d_right,
-                           prm, 0, nb - 1, 2, ws.lpcs, ws.need_full, ws.plans);
+                           prm, 0, nb - 1, 2, ws.lpcs, ws.need_full, ws.plans, (unsigned long long*)nullptr,
+                           (unsigned long long*)nullptr);
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (autost) {

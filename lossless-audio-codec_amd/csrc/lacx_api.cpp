@@ -60,6 +60,8 @@ struct lacx_encoder {
     uint32_t* h_table = nullptr;   // pinned, [blocks][2]
     unsigned long long* h_totals = nullptr;  // pinned, per chunk payload bytes
     uint32_t* h_err = nullptr;     // pinned, per chunk
+    unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: first-start / last-end device clock of k_analyze<16,1024>
+    unsigned long long* h_tspan = nullptr;  // pinned copy
     uint32_t h_table_blocks = 0;
     uint8_t* view_buf = nullptr;   // result of the host-emit fallback kept alive for the *_view API
     uint32_t* view_table = nullptr;
@@ -122,6 +124,8 @@ int ensure_device(lacx_encoder* e) {
     for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * kMaxChunks, 0), "hipHostMalloc");
+    HIP_TRY(e, hipMalloc((void**)&e->d_tspan, sizeof(unsigned long long) * 2 * kMaxChunks), "hipMalloc(tspan)");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_tspan, sizeof(unsigned long long) * 2 * kMaxChunks, 0), "hipHostMalloc");
     e->device_ready = true;
     return LACX_OK;
 }
@@ -546,6 +550,8 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     }
     const unsigned long long* prev_end = nullptr;  // device address of the byte total of the chunks so far
     HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->d_tspan, 0xFF, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->d_tspan + kMaxChunks, 0, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
     HIP_TRY(e, hipStreamSynchronize(st[0]), "synchronize");
     for (size_t c = 0; c < chunks.size(); ++c) {
         const Chunk& ck = chunks[c];
@@ -560,6 +566,8 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
         DeviceWorkspace w = ws_at(e->ws, ck.first);
         w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
         w.err_flag = e->ws.err_flag + c;
+        w.t_first = e->d_tspan + c;
+        w.t_last = e->d_tspan + kMaxChunks + c;
         HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c]), "kernel launch");
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
         HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
@@ -573,6 +581,9 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
         HIP_TRY(e, hipMemcpyAsync(&e->h_totals[c], w.block_off + ck.count, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, s), "D2H total");
         HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
+        HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[c], w.t_first, sizeof(unsigned long long), hipMemcpyDeviceToHost, s), "D2H t");
+        HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[kMaxChunks + c], w.t_last, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, s), "D2H t");
         HIP_TRY(e, hipEventRecord(e->done[c], s), "event record");
     }
     uint64_t off = 0;
@@ -628,6 +639,11 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     }
     e->timing.full_launches = (uint32_t)chunks.size();
     e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
+    e->timing.full_exec_ms = 0;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const unsigned long long a = e->h_tspan[c], b = e->h_tspan[kMaxChunks + c];
+        if (b > a) e->timing.full_exec_ms += (double)(b - a) * 1e-5;  // 100 MHz device clock -> ms
+    }
     *payload_size = off;
     return LACX_OK;
 }
@@ -725,6 +741,8 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
         if (e->h_err) (void)hipHostFree(e->h_err);
+        if (e->h_tspan) (void)hipHostFree(e->h_tspan);
+        if (e->d_tspan) (void)hipFree(e->d_tspan);
         for (auto& s : e->stream)
             if (s) (void)hipStreamDestroy(s);
     }

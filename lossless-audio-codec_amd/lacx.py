@@ -77,6 +77,7 @@ class Timing(C.Structure):
         ("probe_slots", C.c_uint64),
         ("full_launches", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("full_exec_ms", C.c_double),
     ]
 
 
