@@ -283,77 +283,92 @@ LACX_HD uint32_t bytes3(uint32_t lo, uint32_t hi, int sh) {
 LACX_HD bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // The CH consecutive frames of one thread are one contiguous 16-byte-aligned span in every supported layout
-// when the caller's buffer is 16-byte aligned: fetch them with 16-byte loads (a wave then touches each
-// cache line once instead of CH times).  Returns false when the span is not aligned or not a multiple of 16
-// bytes; the caller then takes the per-sample path.  Values are identical either way.
+// when the caller's buffer is 16-byte aligned: they can be fetched with 16-byte loads (a wave then touches each
+// cache line once instead of CH times).  span_ok() says whether that holds for a thread's span; stage_span()
+// does the fetch and must only be called when it does.  Values are identical to the per-sample path.
 template <int CH>
-LACX_HD bool stage_span(const SlotSrc& s, int64_t first, int32_t* v) {
+LACX_HD bool span_ok(const SlotSrc& s, int64_t first) {
     if (s.layout == PCM_PLANAR_I32) {
-        if (CH % 4 != 0) return false;
         const bool needa = s.kind != CH_R, needb = s.kind != CH_L;
-        if ((needa && !aligned16(s.a + first)) || (needb && !aligned16(s.b + first))) return false;
-        uint32_t la[CH] = {}, lb[CH] = {};
-        if (needa) load_vec16<CH / 4>(s.a + first, la);
-        if (needb) load_vec16<CH / 4>(s.b + first, lb);
+        return CH % 4 == 0 && (!needa || aligned16(s.a + first)) && (!needb || aligned16(s.b + first));
+    }
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(s.a);
+    if (s.layout == PCM_INTERLEAVED_I16)
+        return s.channels == 2 ? (CH % 4 == 0 && aligned16(base + first * 4)) : (CH % 8 == 0 && aligned16(base + first * 2));
+    return CH % 16 == 0 && aligned16(base + first * (s.channels == 2 ? 6 : 3));
+}
+
+template <int CH>
+LACX_HD void stage_span(const SlotSrc& s, int64_t first, int32_t* v) {
+    if (s.layout == PCM_PLANAR_I32) {
+        constexpr int NV = CH / 4 > 0 ? CH / 4 : 1;
+        const bool needa = s.kind != CH_R, needb = s.kind != CH_L;
+        uint32_t la[4 * NV] = {}, lb[4 * NV] = {};
+        if (needa) load_vec16<NV>(s.a + first, la);
+        if (needb) load_vec16<NV>(s.b + first, lb);
 #pragma unroll
         for (int i = 0; i < CH; ++i) v[i] = slot_combine(s.kind, (int32_t)la[i], (int32_t)lb[i]);
-        return true;
+        return;
     }
     if (s.layout == PCM_INTERLEAVED_I16) {
         if (s.channels == 2) {
-            if (CH % 4 != 0) return false;
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 4;
-            if (!aligned16(p)) return false;
-            uint32_t w[CH];
-            load_vec16<CH / 4>(p, w);
+            constexpr int NV = CH / 4 > 0 ? CH / 4 : 1;
+            uint32_t w[4 * NV];
+            load_vec16<NV>(reinterpret_cast<const uint8_t*>(s.a) + first * 4, w);
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 v[i] = slot_combine(s.kind, (int32_t)(int16_t)(w[i] & 0xFFFFu), (int32_t)(int16_t)(w[i] >> 16));
-            return true;
+            return;
         }
-        if (CH % 8 != 0) return false;
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 2;
-        if (!aligned16(p)) return false;
-        uint32_t w[CH / 2 > 0 ? CH / 2 : 1];
-        load_vec16<CH / 8>(p, w);
+        constexpr int NV = CH / 8 > 0 ? CH / 8 : 1;
+        uint32_t w[4 * NV];
+        load_vec16<NV>(reinterpret_cast<const uint8_t*>(s.a) + first * 2, w);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = (int32_t)(int16_t)((w[i / 2] >> (16 * (i & 1))) & 0xFFFFu);
-        return true;
+        for (int i = 0; i < CH; ++i) v[i] = (int32_t)(int16_t)((w[(i / 2) % (4 * NV)] >> (16 * (i & 1))) & 0xFFFFu);
+        return;
     }
     // packed 24-bit little-endian
-    if (CH % 16 != 0) return false;
     if (s.channels == 2) {
-        const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 6;
-        if (!aligned16(p)) return false;
-        constexpr int ND = CH * 6 / 4;
-        uint32_t w[ND > 0 ? ND : 1];
-        load_vec16<ND / 4>(p, w);
+        constexpr int ND = CH * 6 / 4 >= 4 ? CH * 6 / 4 : 4;
+        uint32_t w[ND];
+        load_vec16<ND / 4>(reinterpret_cast<const uint8_t*>(s.a) + first * 6, w);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int ol = i * 6, orr = i * 6 + 3;
+            const int ol = (i * 6) % (ND * 4), orr = (i * 6 + 3) % (ND * 4);
             v[i] = slot_combine(s.kind, sext24(bytes3(w[ol / 4], w[(ol / 4 + 1 < ND) ? ol / 4 + 1 : ol / 4], ol & 3)),
                                 sext24(bytes3(w[orr / 4], w[(orr / 4 + 1 < ND) ? orr / 4 + 1 : orr / 4], orr & 3)));
         }
-        return true;
+        return;
     }
-    const uint8_t* p = reinterpret_cast<const uint8_t*>(s.a) + first * 3;
-    if (!aligned16(p)) return false;
-    constexpr int ND = CH * 3 / 4;
-    uint32_t w[ND > 0 ? ND : 1];
-    load_vec16<ND / 4>(p, w);
+    constexpr int ND = CH * 3 / 4 >= 4 ? CH * 3 / 4 : 4;
+    uint32_t w[ND];
+    load_vec16<ND / 4>(reinterpret_cast<const uint8_t*>(s.a) + first * 3, w);
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int o = i * 3;
+        const int o = (i * 3) % (ND * 4);
         v[i] = sext24(bytes3(w[o / 4], w[(o / 4 + 1 < ND) ? o / 4 + 1 : o / 4], o & 3));
     }
-    return true;
+}
+
+// True when the predicate holds in every lane of the wave (a scalar value on the device: branching on it costs
+// one scalar branch, whereas a per-lane condition makes the wave walk through both sides piecewise).
+LACX_HD bool wave_all(bool pred) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(pred) != 0;
+#else
+    return pred;
+#endif
 }
 
 // The CH samples [first, first + CH) of a slot into v[]: one span fetch when all of them exist (cnt == CH) and
-// the span is aligned, else sample by sample with the index clamped to `last` (callers mask what lies beyond).
+// the spans of the whole wave are aligned, else sample by sample with the index clamped to `last` (callers mask
+// what lies beyond).
 template <int CH>
 LACX_HD void load_chunk(const SlotSrc& src, int64_t first, int cnt, int64_t last, int32_t* v) {
-    if (cnt == CH && stage_span<CH>(src, first, v)) return;
+    if (wave_all(cnt == CH && span_ok<CH>(src, first))) {
+        stage_span<CH>(src, first, v);
+        return;
+    }
     // per-sample path: all loads are issued before the first use
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
