@@ -36,12 +36,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def main():
+    global BIT_DEPTH, SAMPLE_RATE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=int, default=SECONDS, help="audio seconds per GPU (default: the 10 min config)")
     ap.add_argument("--kind", default="music")
+    ap.add_argument("--bit-depth", type=int, default=BIT_DEPTH, choices=(16, 24), help="diagnostic: other BASELINE configs")
+    ap.add_argument("--rate", type=int, default=SAMPLE_RATE, choices=(44100, 48000, 96000, 192000))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
@@ -50,6 +53,7 @@ def main():
 
     import torch
 
+    BIT_DEPTH, SAMPLE_RATE = args.bit_depth, args.rate  # locals shadowing the defaults from here on
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,7 +82,8 @@ def main():
     left, right = synth.synth_pcm(frames, 2, BIT_DEPTH, SAMPLE_RATE, seed=2026, kind=args.kind, start=f0)
     interleaved = not (args.planar or args.host_emit or args.analysis_only)
     if interleaved:  # the WAV data-chunk layout: interleaved little-endian int16, 2 bytes per sample in HBM
-        d_pcm = torch.from_numpy(synth.interleave(left, right, BIT_DEPTH).view(np.int16)).cuda()
+        inter = synth.interleave(left, right, BIT_DEPTH)
+        d_pcm = torch.from_numpy(inter.view(np.int16) if BIT_DEPTH == 16 else inter).cuda()
     else:
         d_left = torch.from_numpy(left).cuda()
         d_right = torch.from_numpy(right).cuda()
@@ -98,7 +103,8 @@ def main():
             enc.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
             return None
         if interleaved:
-            payload, table = enc.encode_shard_pcm_device_view(d_pcm.data_ptr(), lacx.PCM_INTERLEAVED_I16, 2, frames, stream)
+            payload, table = enc.encode_shard_pcm_device_view(
+                d_pcm.data_ptr(), lacx.PCM_INTERLEAVED_I16 if BIT_DEPTH == 16 else lacx.PCM_INTERLEAVED_I24, 2, frames, stream)
         else:
             payload, table = enc.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames,
                                                           stream)
@@ -214,7 +220,7 @@ def main():
             "unit": "Msamples/s",
             "cores": cores,
             "kind": kind,
-            "sample": f"first {n_cpu} frames ({n_cpu / SAMPLE_RATE:.0f} s) of the same stereo 16-bit 48 kHz stream, "
+            "sample": f"first {n_cpu} frames ({n_cpu / SAMPLE_RATE:.0f} s) of the same stereo {BIT_DEPTH}-bit {SAMPLE_RATE} Hz stream, "
                       f"{dt:.2f} s wall, {len(data)} B .lac",
         }
 
@@ -232,13 +238,13 @@ def main():
         "dtype": "int64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.seconds} s per GPU synthetic stereo 16-bit 48 kHz ({args.kind}), auto MS/LR, LPC search, "
+            "workload": f"{args.seconds} s per GPU synthetic stereo {BIT_DEPTH}-bit {SAMPLE_RATE // 1000} kHz ({args.kind}), auto MS/LR, LPC search, "
                         "16384-frame blocks, zero-run + partitioning on (BASELINE configs[1])",
             "frames_per_gpu": int(frames),
             "blocks_per_gpu": int(b1 - b0),
             "host_emit_threads": emit_threads,
             "emit": "host" if args.host_emit else "device",
-            "device_pcm_layout": "interleaved int16 (WAV data chunk)" if interleaved else "planar int32",
+            "device_pcm_layout": (f"interleaved int{BIT_DEPTH} (WAV data chunk)" if interleaved else "planar int32"),
             "timed_region": ("device analysis (PCM resident in HBM) + plan D2H + host emit + shard table" if args.host_emit
                              else "device analysis + device bit emit (PCM resident in HBM) + payload/table D2H into pinned host memory")
                             + (" + RCCL all_gather of shard sizes" if world > 1 else ""),
