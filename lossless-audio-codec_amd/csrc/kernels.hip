@@ -530,39 +530,52 @@ __global__ __launch_bounds__(64) void k_stereo(AnalyzeParams prm, const unsigned
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_levinson: one lane per slot
+// k_levinson: one lane per slot that needs it
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_levinson(AnalyzeParams prm, const int64_t* __restrict__ acorr,
-                                                 LpcSet* __restrict__ lpcs) {
-    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t blk = gid / kSlotsPerBlock;
-    const int slot = (int)(gid % kSlotsPerBlock);
-    if (blk >= prm.num_blocks) return;
+constexpr int kLevThreads = 256;
+struct LevMem {  // work arrays R, a, prevA of every thread, one column per thread (120 KiB)
+    uint64_t m[3][13][kLevThreads];
+    uint32_t es[3][13][kLevThreads];  // sign << 31 | (exponent + 2^21)
+};
+
+// The recursion is a serial chain of ~370 software-float operations per slot, so the kernel's duration is one
+// thread's latency whatever the grid looks like.  What the grid decides is how many CUs it takes away from the
+// other pipeline chunks' kernels meanwhile: slots are numbered slot-major (waves made of probe slots of certain
+// blocks leave at once) and packed 256 to a workgroup.
+__global__ __launch_bounds__(kLevThreads) void k_levinson(AnalyzeParams prm, const int64_t* __restrict__ acorr,
+                                                          const uint32_t* __restrict__ need_probe,
+                                                          LpcSet* __restrict__ lpcs) {
+    extern __shared__ __align__(16) unsigned char lev_raw[];
+    LevMem& lm = *reinterpret_cast<LevMem*>(lev_raw);
+    const uint32_t id = blockIdx.x * kLevThreads + threadIdx.x;
+    const uint32_t nblk = prm.num_blocks;
+    const int slot = (int)(id / nblk);
+    const uint32_t blk = id % nblk;
+    if (slot >= kSlotsPerBlock) return;
     const SlotGeom g = slot_geom(prm, blk, slot);
     if (!g.defined) return;
     if (prm.channels == 2 && slot < 4) {
         if (prm.stereo_mode == 0 && (slot & 3) >= 2) return;
         if (prm.stereo_mode == 1 && (slot & 3) < 2) return;
     }
+    if (slot >= 4 && !((need_probe[blk] >> slot) & 1u)) return;  // probe windows of blocks that are not probed
+    const uint32_t gid = blk * kSlotsPerBlock + (uint32_t)slot;
     const int mvo = (g.n > 1) ? (int)((g.n - 1 < 32u) ? g.n - 1 : 32u) : 0;
-    // work arrays in LDS, one column per thread (indexed by loop variables: as locals they would be scratch)
-    __shared__ uint64_t s_m[3][13][64];
-    __shared__ int32_t s_e[3][13][64];
-    __shared__ uint32_t s_s[3][13][64];
     struct LdsArray {
-        uint64_t (*m)[64];
-        int32_t (*e)[64];
-        uint32_t (*s)[64];
+        uint64_t (*m)[kLevThreads];
+        uint32_t (*es)[kLevThreads];
         int lane;
-        __device__ xf80 get(int i) const { return xf80{m[i][lane], e[i][lane], s[i][lane]}; }
+        __device__ xf80 get(int i) const {
+            const uint32_t w = es[i][lane];
+            return xf80{m[i][lane], (int32_t)(w & 0x7FFFFFFFu) - (1 << 21), w >> 31};
+        }
         __device__ void set(int i, xf80 x) {
             m[i][lane] = x.m;
-            e[i][lane] = x.e;
-            s[i][lane] = x.s;
+            es[i][lane] = (x.s << 31) | ((uint32_t)(x.e + (1 << 21)) & 0x7FFFFFFFu);
         }
     };
     const int lane = (int)threadIdx.x;
-    LdsArray Rv{s_m[0], s_e[0], s_s[0], lane}, av{s_m[1], s_e[1], s_s[1], lane}, pv{s_m[2], s_e[2], s_s[2], lane};
+    LdsArray Rv{lm.m[0], lm.es[0], lane}, av{lm.m[1], lm.es[1], lane}, pv{lm.m[2], lm.es[2], lane};
     const int64_t* r = acorr + (size_t)gid * 13;
     LpcSet* out = &lpcs[gid];
     levinson_candidates_t([r](int i) { return r[i]; }, mvo, Rv, av, pv,
@@ -1173,6 +1186,9 @@ static hipError_t set_smem_attr() {
         cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GFull>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GFull>));
         if (cached == hipSuccess)
+            cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_levinson),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LevMem));
+        if (cached == hipSuccess)
             cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
         done = true;
@@ -1193,8 +1209,8 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
                        ws.badidx, ws.acorr);
     hipLaunchKernelGGL(k_stereo, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, ws.sums, ws.badidx, ws.bplans,
                        ws.need_probe, ws.need_full);
-    hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + 63) / 64), dim3(64), 0, stream, prm, ws.acorr,
-                       ws.lpcs);
+    hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
+                       sizeof(LevMem), stream, prm, ws.acorr, ws.need_probe, ws.lpcs);
     if (ev) (void)hipEventRecord(ev[1], stream);
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     if (autost) {
