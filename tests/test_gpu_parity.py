@@ -282,3 +282,37 @@ def test_config5_every_format_combination(gpu, oracle):
                 sm = 2 if ch == 2 else 0
                 got = gpu.lacx.Encoder(12, sm, sr, bd).encode(left, right)
                 assert got == oracle.encode(left, right, sr, bd, sm, threads=8), (ch, bd, sr)
+
+
+def test_random_sweep(gpu, oracle):
+    """Randomised shapes, material, levels and flags (a short run of scripts/fuzz_blocks.py's sweep)."""
+    rng = np.random.default_rng(20261003)
+    kinds = ["music", "noise", "silence", "near_silence", "sparse", "ramp", "walk", "tone", "mixed"]
+    stereos = ["wide", "narrow", "identical", "anticorr", "independent"]
+    for it in range(60):
+        ch = int(rng.integers(1, 3))
+        bd = int(rng.choice([16, 24]))
+        sr = int(rng.choice([44100, 48000, 96000, 192000]))
+        sm = int(rng.integers(0, 3)) if ch == 2 else 0
+        frames = int(rng.choice([1, 33, 4095, 4097, 16383, 16385, int(rng.integers(1, 50000))]))
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=int(rng.integers(1, 10**6)), kind=str(rng.choice(kinds)),
+                                          stereo=str(rng.choice(stereos)), start=int(rng.integers(0, 10**6)))
+        if rng.random() < 0.3:
+            sh = int(rng.integers(1, bd - 1))
+            left = (left >> sh).astype(np.int32)
+            right = None if right is None else (right >> sh).astype(np.int32)
+        zr, pt = bool(rng.random() < 0.85), bool(rng.random() < 0.85)
+        enc = gpu.lacx.Encoder(12, sm, sr, bd)
+        enc.set_zero_run_enabled(zr)
+        enc.set_partitioning_enabled(pt)
+        enc.set_host_emit(bool(rng.random() < 0.3))
+        assert enc.encode(left, right) == oracle.encode(left, right, sr, bd, sm, zero_run=zr, partitioning=pt, threads=8), \
+            (it, ch, bd, sr, sm, frames, zr, pt)
+    be = gpu.lacx.BlockEncoder()
+    for it in range(200):
+        n = int(rng.choice([1, 2, 13, 31, 32, 33, 255, 256, 257, 4096, 16384, int(rng.integers(1, 16385))]))
+        x, _ = gpu.synth.synth_pcm(n, 1, 24, 48000, seed=int(rng.integers(1, 10**6)), kind=str(rng.choice(kinds)),
+                                   start=int(rng.integers(0, 10**6)))
+        if rng.random() < 0.4:
+            x = (x >> int(rng.integers(1, 23))).astype(np.int32)
+        assert be.encode(x) == oracle.block_encode(x), (it, n)
