@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
+    ap.add_argument("--inflight", type=int, default=1, choices=(1, 2),
+                    help="diagnostic: 2 = the next step is enqueued on a second encoder before the previous step's result "
+                         "is collected (measured slower: the two encodes' kernels time-slice the CUs)")
     ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
     args = ap.parse_args()
 
@@ -89,46 +92,68 @@ def main():
         d_right = torch.from_numpy(right).cuda()
     torch.cuda.synchronize()
 
-    enc = lacx.Encoder(12, STEREO_MODE, SAMPLE_RATE, BIT_DEPTH, device=local_rank)
     host_cores = os.cpu_count() or 1
     # host emit workers: the box's CPU share per GPU (16), overridable for tuning
     share = max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     emit_threads = int(os.environ.get("LACX_EMIT_THREADS", "0")) or min(16, share)
-    enc.set_thread_count(emit_threads)
-    enc.set_host_emit(args.host_emit)
+    inflight = args.inflight if interleaved else 1
+    encs = []
+    for _ in range(inflight):
+        e_ = lacx.Encoder(12, STEREO_MODE, SAMPLE_RATE, BIT_DEPTH, device=local_rank)
+        e_.set_thread_count(emit_threads)
+        e_.set_host_emit(args.host_emit)
+        encs.append(e_)
+    enc = encs[0]
     stream = torch.cuda.current_stream().cuda_stream
+    layout = lacx.PCM_INTERLEAVED_I16 if BIT_DEPTH == 16 else lacx.PCM_INTERLEAVED_I24
 
-    def step():
-        if args.analysis_only:
-            enc.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
-            return None
-        if interleaved:
-            payload, table = enc.encode_shard_pcm_device_view(
-                d_pcm.data_ptr(), lacx.PCM_INTERLEAVED_I16 if BIT_DEPTH == 16 else lacx.PCM_INTERLEAVED_I24, 2, frames, stream)
-        else:
-            payload, table = enc.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames,
-                                                          stream)
+    def exchange(table):
         if world > 1:
             sizes = torch.from_numpy(table[:, 1].astype(np.int64)).cuda()
             mine = torch.tensor([int(sizes.sum().item()), table.shape[0]], dtype=torch.int64, device="cuda")
             allv = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
-        return payload, table
+
+    def begin(i):  # enqueue step i (returns at once on the interleaved device-emit path)
+        e_ = encs[i % inflight]
+        if args.analysis_only:
+            e_.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
+        elif interleaved:
+            e_.encode_shard_pcm_device_begin(d_pcm.data_ptr(), layout, 2, frames, stream)
+
+    def end(i):  # collect step i: payload + block table of the shard on the host
+        e_ = encs[i % inflight]
+        if args.analysis_only:
+            return None, e_.timing()
+        if interleaved:
+            payload, table = e_.encode_shard_end()
+        else:
+            payload, table = e_.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames, stream)
+        exchange(table)
+        return (payload, table), e_.timing()
+
+    def run(nsteps, record):
+        last_ = None
+        for i in range(nsteps):
+            begin(i)
+            if i >= inflight - 1:
+                last_, t = end(i - (inflight - 1))
+                record(t)
+        for j in range(max(0, nsteps - (inflight - 1)), nsteps):
+            last_, t = end(j)
+            record(t)
+        return last_
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup, lambda t: None)
     sync()
     full_ms, analysis_ms, emit_ms, probe_ms, ingest_ms, launches, api_ms, exec_ms = [], [], [], [], [], [], [], []
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-        t = enc.timing()
+
+    def record(t):
         full_ms.append(t.full_ms)
         analysis_ms.append(t.analysis_ms)
         emit_ms.append(t.emit_ms)
@@ -137,6 +162,9 @@ def main():
         launches.append(max(1, t.full_launches))
         api_ms.append(t.total_ms)
         exec_ms.append(t.full_exec_ms)
+
+    t0 = time.perf_counter()
+    last = run(args.steps, record)
     sync()
     elapsed = time.perf_counter() - t0
     tm = enc.timing()
@@ -244,6 +272,7 @@ def main():
             "blocks_per_gpu": int(b1 - b0),
             "host_emit_threads": emit_threads,
             "emit": "host" if args.host_emit else "device",
+            "encodes_in_flight": inflight,
             "device_pcm_layout": (f"interleaved int{BIT_DEPTH} (WAV data chunk)" if interleaved else "planar int32"),
             "timed_region": ("device analysis (PCM resident in HBM) + plan D2H + host emit + shard table" if args.host_emit
                              else "device analysis + device bit emit (PCM resident in HBM) + payload/table D2H into pinned host memory")

@@ -161,6 +161,15 @@ int lacx_encode_shard_pcm_device_view(lacx_encoder* enc, const lacx_pcm* d_pcm, 
                                       const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
                                       uint32_t* nblocks);
 
+/* The same in two halves, for batch jobs (many files or shards through one process): _begin enqueues the whole
+ * encode on the device and returns without waiting; _end waits for it and hands the result over.  One encode can be
+ * in flight per encoder; with two encoders used alternately (begin A, end B, begin B, end A, ...) the device analyses
+ * the next input while the previous one's last emit kernels are still pushing their payload over PCIe.  The result
+ * views stay valid until the same encoder's next _begin. */
+int lacx_encode_shard_pcm_device_begin(lacx_encoder* enc, const lacx_pcm* d_pcm, uint64_t frames, void* stream);
+int lacx_encode_shard_end(lacx_encoder* enc, const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                          uint32_t* nblocks);
+
 /* WAV ingest (replaces read_wav + LAC::Encoder::encode of the CLI's encode command,
  * ref src/io/wav_io.cpp:167-277, src/main.cpp:640-675).  lacx_wav_parse walks the RIFF container in memory and
  * accepts / rejects exactly the files read_wav does (LACX_OK / LACX_E_INVALID, no device needed); lacx_encode_wav

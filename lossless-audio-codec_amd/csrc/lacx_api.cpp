@@ -32,6 +32,10 @@ namespace {
 constexpr int kStreams = 4;
 constexpr int kMaxChunks = 16;
 constexpr uint32_t kMinChunkBlocks = 192;  // >= 1.5 rounds of 1024-thread workgroups over 256 CUs
+using clk = std::chrono::steady_clock;
+struct Chunk {
+    uint32_t first, count;
+};
 }  // namespace
 
 struct lacx_encoder {
@@ -53,6 +57,17 @@ struct lacx_encoder {
     // device emit
     uint8_t* d_payload = nullptr;
     uint64_t d_payload_cap = 0;
+    // device-emit encode in flight between encode_device_begin and encode_device_end
+    struct {
+        bool active = false;
+        std::vector<Chunk> chunks;
+        uint32_t nb = 0;
+        int channels = 0;
+        bool staged = false;
+        hipStream_t st[4] = {};
+        clk::time_point t0;
+    } pend;
+    hipEvent_t prologue = nullptr;  // per-call memsets done (the chunk streams wait for it)
     uint8_t* d_raw = nullptr;  // WAV data chunk as read from the file (lacx_encode_wav)
     uint64_t d_raw_cap = 0;
     uint8_t* h_payload = nullptr;  // pinned
@@ -72,7 +87,6 @@ struct lacx_encoder {
 
 namespace {
 
-using clk = std::chrono::steady_clock;
 double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
 int fail(lacx_encoder* e, int code, const std::string& msg) {
@@ -122,6 +136,7 @@ int ensure_device(lacx_encoder* e) {
         for (auto& ev : row) HIP_TRY(e, hipEventCreate(&ev), "hipEventCreate");
     for (auto& ev : e->done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    HIP_TRY(e, hipEventCreateWithFlags(&e->prologue, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * kMaxChunks, 0), "hipHostMalloc");
     HIP_TRY(e, hipMalloc((void**)&e->d_tspan, sizeof(unsigned long long) * 2 * kMaxChunks), "hipMalloc(tspan)");
@@ -248,10 +263,6 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
     w.table += (size_t)first_block * 2;
     return w;
 }
-
-struct Chunk {
-    uint32_t first, count;
-};
 
 // Host emit wants many chunks (emit of chunk i overlaps the analysis of chunk i+1); with the emit on the
 // device the only host work is a copy, and two chunks (payload copy of one under the kernels of the other)
@@ -496,14 +507,17 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
 // kernel straight into one pinned host buffer at global byte offsets (chunk c starts where chunk c-1 ends).
 // Results stay in encoder-owned pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
 // pinned buffer was too small (the caller then falls back to the host-emit pipeline, same bytes).
-int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
-                            hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0) {
+// Part 1: enqueue everything (no host synchronisation).
+int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                        hipStream_t user_stream, int layout = 0, int layout_channels = 0) {
+    if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
     const int channels = layout ? layout_channels : (d_right ? 2 : 1);
     const uint64_t frame_bytes = layout == 1 ? 2ull * channels : (layout == 2 ? 3ull * channels : 4ull);
     const uint32_t nb = blocks_for(frames);
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
-    const std::vector<Chunk> chunks = plan_chunks(nb, true);
+    e->pend.chunks = plan_chunks(nb, true);
+    const std::vector<Chunk>& chunks = e->pend.chunks;
     // Destination of k_emit: by default the pinned host buffer itself (the kernel's 16-byte stores cross PCIe
     // while later blocks are still being analysed, so no separate D2H pass is left at the end); with
     // LACX_EMIT_STAGED=1 a device arena sized for the worst case (12 bytes per sample), copied afterwards.
@@ -552,10 +566,11 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, st[0]), "memset");
     HIP_TRY(e, hipMemsetAsync(e->d_tspan, 0xFF, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
     HIP_TRY(e, hipMemsetAsync(e->d_tspan + kMaxChunks, 0, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
-    HIP_TRY(e, hipStreamSynchronize(st[0]), "synchronize");
+    HIP_TRY(e, hipEventRecord(e->prologue, st[0]), "event record");
     for (size_t c = 0; c < chunks.size(); ++c) {
         const Chunk& ck = chunks[c];
         hipStream_t s = st[c % kStreams];
+        if (c % kStreams != 0) HIP_TRY(e, hipStreamWaitEvent(s, e->prologue, 0), "stream wait");
         const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
         const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
         const AnalyzeParams prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
@@ -586,6 +601,26 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
                                   hipMemcpyDeviceToHost, s), "D2H t");
         HIP_TRY(e, hipEventRecord(e->done[c], s), "event record");
     }
+    e->pend.active = true;
+    e->pend.nb = nb;
+    e->pend.channels = channels;
+    e->pend.staged = staged;
+    for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
+    e->pend.t0 = t0;
+    return LACX_OK;
+}
+
+// Part 2: wait for the chunks in order, check them, hand the result over.  Returns LACX_OK, an error, or -1 when
+// the reservation of the pinned buffer was too small.
+int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
+    if (!e->pend.active) return fail(e, LACX_E_RUNTIME, "no encode in flight on this encoder");
+    e->pend.active = false;
+    const std::vector<Chunk>& chunks = e->pend.chunks;
+    const uint32_t nb = e->pend.nb;
+    const int channels = e->pend.channels;
+    const bool staged = e->pend.staged;
+    hipStream_t* st = e->pend.st;
+    const auto t0 = e->pend.t0;
     uint64_t off = 0;
     int status = LACX_OK;
     size_t copies = 0;
@@ -646,6 +681,13 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
     }
     *payload_size = off;
     return LACX_OK;
+}
+
+int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                            hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0) {
+    const int rc = encode_device_begin(e, d_left, d_right, frames, user_stream, layout, layout_channels);
+    if (rc) return rc;
+    return encode_device_end(e, payload_size);
 }
 
 int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
@@ -735,6 +777,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
             if (ev) (void)hipEventDestroy(ev);
         for (auto& ev : e->copied)
             if (ev) (void)hipEventDestroy(ev);
+        if (e->prologue) (void)hipEventDestroy(e->prologue);
         if (e->d_payload) (void)hipFree(e->d_payload);
         if (e->d_raw) (void)hipFree(e->d_raw);
         if (e->h_payload) (void)hipHostFree(e->h_payload);
@@ -967,6 +1010,43 @@ int lacx_encode_shard_device_view(lacx_encoder* e, const int32_t* d_left, const 
     return LACX_OK;
 }
 
+int lacx_encode_shard_pcm_device_begin(lacx_encoder* e, const lacx_pcm* pcm, uint64_t frames, void* stream) {
+    if (!e || !pcm) return LACX_E_INVALID;
+    e->timing = lacx_timing{};
+    int rc = prepare(e, pcm->data0, frames);
+    if (rc) return rc;
+    if (pcm->channels != 1 && pcm->channels != 2) return fail(e, LACX_E_INVALID, "unsupported channel count");
+    if (e->cfg.flags & LACX_FLAG_HOST_EMIT)
+        return fail(e, LACX_E_INVALID, "the begin/end interface needs the device-side emit");
+    if (pcm->layout == LACX_PCM_PLANAR_I32) {
+        if ((pcm->channels == 2) != (pcm->data1 != nullptr))
+            return fail(e, LACX_E_INVALID, "planar PCM: data1 must be the right channel of stereo input and null for mono");
+        return encode_device_begin(e, static_cast<const int32_t*>(pcm->data0), static_cast<const int32_t*>(pcm->data1), frames,
+                                   static_cast<hipStream_t>(stream));
+    }
+    const int want_depth = pcm->layout == LACX_PCM_INTERLEAVED_I16 ? 16 : (pcm->layout == LACX_PCM_INTERLEAVED_I24 ? 24 : 0);
+    if (want_depth == 0) return fail(e, LACX_E_INVALID, "unknown PCM layout");
+    if (e->cfg.bit_depth != want_depth) return fail(e, LACX_E_INVALID, "PCM layout does not match the configured bit depth");
+    return encode_device_begin(e, static_cast<const int32_t*>(pcm->data0), nullptr, frames, static_cast<hipStream_t>(stream),
+                               (int)pcm->layout, (int)pcm->channels);
+}
+
+int lacx_encode_shard_end(lacx_encoder* e, const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
+                          uint32_t* nblocks) {
+    if (!e || !payload || !payload_size || !table || !nblocks) return LACX_E_INVALID;
+    const uint32_t nb = e->pend.nb;
+    uint64_t pay = 0;
+    const int rc = encode_device_end(e, &pay);
+    if (rc == -1) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
+    if (rc) return rc;
+    *payload = e->h_payload;
+    *payload_size = pay;
+    *table = e->h_table;
+    *nblocks = nb;
+    e->timing.total_ms = ms_since(e->pend.t0);
+    return LACX_OK;
+}
+
 int lacx_encode_shard_pcm_device_view(lacx_encoder* e, const lacx_pcm* pcm, uint64_t frames, void* stream,
                                       const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
                                       uint32_t* nblocks) {
@@ -975,27 +1055,9 @@ int lacx_encode_shard_pcm_device_view(lacx_encoder* e, const lacx_pcm* pcm, uint
         return lacx_encode_shard_device_view(e, static_cast<const int32_t*>(pcm->data0),
                                              static_cast<const int32_t*>(pcm->data1), nullptr, nullptr, frames, stream,
                                              payload, payload_size, table, nblocks);
-    const auto t0 = clk::now();
-    e->timing = lacx_timing{};
-    int rc = prepare(e, pcm->data0, frames);
+    const int rc = lacx_encode_shard_pcm_device_begin(e, pcm, frames, stream);
     if (rc) return rc;
-    if (pcm->channels != 1 && pcm->channels != 2) return fail(e, LACX_E_INVALID, "unsupported channel count");
-    const int want_depth = pcm->layout == LACX_PCM_INTERLEAVED_I16 ? 16 : (pcm->layout == LACX_PCM_INTERLEAVED_I24 ? 24 : 0);
-    if (want_depth == 0) return fail(e, LACX_E_INVALID, "unknown PCM layout");
-    if (e->cfg.bit_depth != want_depth) return fail(e, LACX_E_INVALID, "PCM layout does not match the configured bit depth");
-    if (e->cfg.flags & LACX_FLAG_HOST_EMIT)
-        return fail(e, LACX_E_INVALID, "interleaved device PCM needs the device-side emit");
-    uint64_t pay = 0;
-    rc = encode_pipelined_device(e, static_cast<const int32_t*>(pcm->data0), nullptr, frames,
-                                 static_cast<hipStream_t>(stream), &pay, (int)pcm->layout, (int)pcm->channels);
-    if (rc == -1) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
-    if (rc) return rc;
-    *payload = e->h_payload;
-    *payload_size = pay;
-    *table = e->h_table;
-    *nblocks = blocks_for(frames);
-    e->timing.total_ms = ms_since(t0);
-    return LACX_OK;
+    return lacx_encode_shard_end(e, payload, payload_size, table, nblocks);
 }
 
 int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,

@@ -86,7 +86,7 @@ EXPORTS = (
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
-    "lacx_encode_wav",
+    "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end",
 )
 
 
@@ -307,6 +307,28 @@ class Encoder:
         rc = lib().lacx_encode_shard_device_view(h, C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr or 0), hlp, hrp,
                                                  C.c_uint64(frames), C.c_void_p(stream), C.byref(pay),
                                                  C.byref(psize), C.byref(tab), C.byref(nb))
+        if rc != OK:
+            _raise(h, rc)
+        table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))
+        return PayloadView(pay, psize.value), table
+
+    def encode_shard_pcm_device_begin(self, data_ptr: int, layout: int, channels: int, frames: int, stream: int = 0,
+                                      data1_ptr: int | None = None):
+        """Enqueues a shard encode of device-resident PCM and returns at once (see encode_shard_end)."""
+        pcm = Pcm(data_ptr, data1_ptr, layout, channels)
+        h = self._handle()
+        rc = lib().lacx_encode_shard_pcm_device_begin(h, C.byref(pcm), C.c_uint64(frames), C.c_void_p(stream))
+        if rc != OK:
+            _raise(h, rc)
+
+    def encode_shard_end(self):
+        """Waits for the encode started by encode_shard_pcm_device_begin: (PayloadView, table)."""
+        pay = C.POINTER(C.c_uint8)()
+        psize = C.c_uint64()
+        tab = C.POINTER(C.c_uint32)()
+        nb = C.c_uint32()
+        h = self._handle()
+        rc = lib().lacx_encode_shard_end(h, C.byref(pay), C.byref(psize), C.byref(tab), C.byref(nb))
         if rc != OK:
             _raise(h, rc)
         table = np.ctypeslib.as_array(tab, shape=(nb.value, 2))

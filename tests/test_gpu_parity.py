@@ -316,3 +316,28 @@ def test_random_sweep(gpu, oracle):
         if rng.random() < 0.4:
             x = (x >> int(rng.integers(1, 23))).astype(np.int32)
         assert be.encode(x) == oracle.block_encode(x), (it, n)
+
+
+def test_begin_end_interface(gpu, oracle):
+    """The two-halves interface (enqueue, collect later) with two encoders alternating: same bytes."""
+    import torch
+
+    sr, bd, sm = 48000, 16, 2
+    streams = []
+    for seed in (41, 42, 43):
+        left, right = gpu.synth.synth_pcm(16384 * 3 + 1000 * seed % 7000 + 5, 2, bd, sr, seed=seed, kind="mixed")
+        d = torch.from_numpy(gpu.synth.interleave(left, right, bd).view(np.int16)).cuda()
+        streams.append((left, right, d))
+    encs = [gpu.lacx.Encoder(12, sm, sr, bd), gpu.lacx.Encoder(12, sm, sr, bd)]
+    got = []
+    for i, (left, right, d) in enumerate(streams):
+        encs[i % 2].encode_shard_pcm_device_begin(d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16, 2, left.size)
+        if i >= 1:
+            p, t = encs[(i - 1) % 2].encode_shard_end()
+            got.append((p.tobytes(), t.copy()))
+    p, t = encs[(len(streams) - 1) % 2].encode_shard_end()
+    got.append((p.tobytes(), t.copy()))
+    for (left, right, _), (p, t) in zip(streams, got):
+        assert gpu.lacx.assemble(sr, bd, sm, 2, [(p, t)]) == oracle.encode(left, right, sr, bd, sm, threads=8)
+    with pytest.raises(RuntimeError, match="no encode in flight"):
+        encs[0].encode_shard_end()
