@@ -12,7 +12,10 @@
 //   k_analyze<16,1024>  one 1024-thread workgroup per needed whole-block slot
 //                                                           (ref block/encoder.cpp:313-552)
 //   k_decide(2) small-block full comparison (ref lac/encoder.cpp:336-340), final BlockPlan
-// The bit-serial emit stays on the host (emit.cpp), driven by the ChannelPlan records.
+//   k_offsets   one workgroup: block byte sizes -> payload offsets + the container's block table
+//   k_emit<16,1024>     one workgroup per chosen channel block: the bitstream, written straight into the
+//                       (pinned host) result buffer                 (ref block/encoder.cpp:554-838)
+// The host emit (emit.cpp, LACX_FLAG_HOST_EMIT) consumes the same ChannelPlan records instead of k_offsets/k_emit.
 #include <hip/hip_runtime.h>
 
 #include "analyze_core.h"
@@ -49,16 +52,6 @@ __device__ unsigned long long g_stamp_acc[32];
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64);
-    const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, d, 64);
-    const uint32_t hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
 // Wave-wide inclusive scans and reductions on the DPP network (gfx9 row_shr / row_bcast), which is part of the
 // VALU pipeline: six full-rate moves per scan instead of six trips through the LDS crossbar (ds_bpermute).
 //   row_shr:n       lane i of a 16-lane row reads lane i-n of the same row
@@ -279,13 +272,11 @@ __device__ __forceinline__ SlotSrc slot_src(const AnalyzeParams& prm, const int3
     return s;
 }
 
-// first frame of block `blk` of the shard, as an index slot_fetch understands
-__device__ __forceinline__ int64_t block_start(uint32_t blk) { return (int64_t)blk * kMaxBlock; }
 
 // ---------------------------------------------------------------------------------------------
 // k_ingest: one workgroup per (block, channel in L,R,M,S)
-//   * coalesced loads of the channel (M/S derived on the fly) into LDS tiles of 1024 samples + 12 of
-//     history, 13-lag exact int64 autocorrelation of the whole block from the tiles (lpc.cpp:80-96);
+//   * span loads of the channel (M/S derived on the fly), 16 consecutive samples per thread and 4096-sample tile,
+//     neighbours' history through LDS, 13-lag exact int64 autocorrelation of the whole block (lpc.cpp:80-96);
 //   * the three 256-frame probe windows (lac/encoder.cpp:343-346) as three more small passes;
 //   * the channel's three proxy sums of estimate_stereo_mode (lac/encoder.cpp:146-178) and the sample
 //     range validation (lac/encoder.cpp:82-102).
