@@ -269,7 +269,9 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
 // measured best.
 std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false) {
     uint32_t nchunks = nb / kMinChunkBlocks;
-    nchunks = std::max(1u, std::min(nchunks, device_emit ? 3u : 8u));
+    // device emit: 3 chunks up to an hour of stereo 48 kHz per call, 4 and 6 beyond (measured on a 2 h shard)
+    const uint32_t dev_chunks = nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u);
+    nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
         const unsigned long v = std::strtoul(env, nullptr, 0);
