@@ -5,7 +5,7 @@
 #include <cstdint>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-__global__ __launch_bounds__(1024) void k_probe(const uint4* __restrict__ in, uint32_t* out, unsigned long long* acc, int spin0, int jitter, int pair, int heavy) {
+__global__ __launch_bounds__(1024) void k_probe(const uint4* __restrict__ in, uint32_t* out, unsigned long long* acc, int spin0, int jitter, int pair, int heavy, int tail) {
     extern __shared__ uint32_t lds[];
     if (threadIdx.x == 0) lds[0] = 1;
     int spin = spin0;
@@ -30,6 +30,10 @@ __global__ __launch_bounds__(1024) void k_probe(const uint4* __restrict__ in, ui
         for (int i = 0; i < spin; ++i) x = x * 1664525u + 1013904223u;
     }
     out[(size_t)blockIdx.x * 1024 + threadIdx.x] = x;
+    if (tail && threadIdx.x == 0) {  // a plan record written by one lane, byte by byte
+        volatile unsigned char* pb = reinterpret_cast<volatile unsigned char*>(out) + (size_t)blockIdx.x * 4096 + 8192u * 1024u;
+        for (int i = 0; i < 300; ++i) pb[i] = (unsigned char)(x + i);
+    }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&acc[0], t1 - t0);
         atomicAdd(&acc[1], 1ull);
@@ -39,21 +43,22 @@ __global__ __launch_bounds__(1024) void k_probe(const uint4* __restrict__ in, ui
 int main() {
     const int nwg = 3516;
     uint4* in; uint32_t* out; unsigned long long* acc;
-    CHECK(hipMalloc(&in, (size_t)nwg * 65536)); CHECK(hipMalloc(&out, (size_t)nwg * 4096)); CHECK(hipMalloc(&acc, 16));
+    CHECK(hipMalloc(&in, (size_t)nwg * 65536)); CHECK(hipMalloc(&out, (size_t)nwg * 4096 * 2 + (8192u * 1024u))); CHECK(hipMalloc(&acc, 16));
     CHECK(hipMemset(in, 1, (size_t)nwg * 65536));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     for (int cfg = 0; cfg < 4; ++cfg) {
         const int spin = 400000;
         const int jitter = cfg & 1;
         const int pair = 0;
-        const int heavy = cfg >> 1;
+        const int heavy = 0;
+        const int tail = cfg >> 1;
         const int ldsb = 120 * 1024;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipMemset(acc, 0, 16));
-            hipLaunchKernelGGL(k_probe, dim3(nwg), dim3(1024), ldsb, 0, in, out, acc, spin, jitter, pair, heavy);
+            hipLaunchKernelGGL(k_probe, dim3(nwg), dim3(1024), ldsb, 0, in, out, acc, spin, jitter, pair, heavy, tail);
             CHECK(hipDeviceSynchronize());
             unsigned long long h[2]; CHECK(hipMemcpy(h, acc, 16, hipMemcpyDeviceToHost));
-            if (rep == 2) printf("heavy %d pair %d spin %6d jitter %d lds %6d: first-load latency %.0f shader cycles per wave (avg over %llu waves)\n", heavy, pair, spin, jitter, ldsb, (double)h[0] / h[1], h[1]);
+            if (rep == 2) printf("tail %d heavy %d pair %d spin %6d jitter %d lds %6d: first-load latency %.0f shader cycles per wave (avg over %llu waves)\n", tail, heavy, pair, spin, jitter, ldsb, (double)h[0] / h[1], h[1]);
         }
     }
     return 0;
