@@ -1019,7 +1019,7 @@ int lacx_encode_shard_pcm_device_begin(lacx_encoder* e, const lacx_pcm* pcm, uin
     if (rc) return rc;
     if (pcm->channels != 1 && pcm->channels != 2) return fail(e, LACX_E_INVALID, "unsupported channel count");
     if (e->cfg.flags & LACX_FLAG_HOST_EMIT)
-        return fail(e, LACX_E_INVALID, "the begin/end interface needs the device-side emit");
+        return fail(e, LACX_E_INVALID, "this entry point needs the device-side emit (LACX_FLAG_HOST_EMIT is set)");
     if (pcm->layout == LACX_PCM_PLANAR_I32) {
         if ((pcm->channels == 2) != (pcm->data1 != nullptr))
             return fail(e, LACX_E_INVALID, "planar PCM: data1 must be the right channel of stereo input and null for mono");
