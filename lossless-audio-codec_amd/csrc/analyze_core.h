@@ -200,7 +200,7 @@ struct PartMem {
 
 template <class G>
 struct Smem {
-    uint32_t u[G::MAXN];  // zigzag residual of the current candidate (transposed); bits 30/31 = micro flags
+    uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate (transposed); bits 30/31 = micro flags; +4: peek_u looks up to 3 samples past the slot
     union XP {
         int32_t x[G::MAXN];  // staged samples (transposed), zero beyond n
         PartMem<G> part;
@@ -574,7 +574,7 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
 }
 
 // Sample j as seen by the zero-run lookahead: its u, or 1 ("not a zero") at/after `limit`.
-// j may run up to 3 past the slot; the read then lands in the words that follow u[] and is discarded.
+// j may run up to 3 past the slot; the read then lands in the pad words at the end of u[] and is discarded.
 template <class G, class M>
 LACX_HD uint32_t peek_u(const M& sh, uint32_t j, uint32_t limit) {
     const uint32_t idx = (j % (uint32_t)G::CH) * (uint32_t)G::T + (j / (uint32_t)G::CH);

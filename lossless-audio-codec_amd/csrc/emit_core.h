@@ -19,7 +19,7 @@ constexpr int kEmitTileWords = 12288;  // 48 KiB output tile (393216 bits)
 
 template <class G>
 struct EmitMem {
-    uint32_t u[G::MAXN];  // zigzag residual (transposed); bits 30/31 = micro flags during the stateful walk
+    uint32_t u[G::MAXN + 4];  // zigzag residual (transposed); bits 30/31 = micro flags during the stateful walk; +4: lookahead pad
     union XP {
         int32_t x[G::MAXN];  // staged samples until the residual is formed
         struct Out {
