@@ -78,3 +78,19 @@ def test_simulated_kernel_plans_match_oracle(pkg, oracle, sim, kind):
             _check(sim, oracle, x, geo, True, True, wide)
     _check(sim, oracle, left[:16384], 0, False, True, 0)
     _check(sim, oracle, left[:16384], 0, True, False, 0)
+
+
+def test_kernel_phases_clean_under_sanitizers():
+    """The phase code the HIP kernels are built from, compiled for the host with AddressSanitizer + UBSan and run
+    over block shapes and materials that reach every path (narrow / 64-bit, zero-run, bin, partitions, emit tiles)."""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "sim_sanitize")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC,
+           os.path.join(ROOT, "tests", "native", "sim_analyze.cpp"),
+           os.path.join(ROOT, "tests", "native", "sim_sanitize_main.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and ("asan" in built.stderr or "ubsan" in built.stderr or "sanitize" in built.stderr):
+        pytest.skip("sanitizer runtime not available: " + built.stderr.strip().splitlines()[-1])
+    assert built.returncode == 0, built.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0 and "sanitized simulator runs" in run.stdout, run.stdout + run.stderr
