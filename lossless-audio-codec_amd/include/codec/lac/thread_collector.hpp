@@ -1,23 +1,32 @@
-// Mirror of the reference's src/codec/lac/thread_collector.hpp:8-23: kept so that callers passing a
-// ThreadCollector* compile unchanged.  The GPU path has no per-block CPU workers; the collector records
-// the calling thread only.
+// LAC::ThreadCollector with the reference's interface (src/codec/lac/thread_collector.hpp:8-23: record(id),
+// snapshot()), kept so that callers handing one to LAC::Encoder::encode compile unchanged.  The MI355X path has
+// no per-block CPU workers: the encoder records the calling thread.
 #pragma once
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <thread>
+#include <vector>
+
+namespace LAC {
 
 class ThreadCollector {
 public:
-    void record(std::thread::id id) {
-        std::lock_guard<std::mutex> lock(mutex_);
-        ids_.insert(id);
+    // Remembers a thread id (idempotent).
+    void record(std::thread::id who) {
+        const std::scoped_lock guard(lock_);
+        if (std::find(seen_.begin(), seen_.end(), who) == seen_.end()) seen_.push_back(who);
     }
-    std::size_t count() const {
-        std::lock_guard<std::mutex> lock(mutex_);
-        return ids_.size();
+
+    // The distinct ids recorded so far.
+    std::set<std::thread::id> snapshot() const {
+        const std::scoped_lock guard(lock_);
+        return std::set<std::thread::id>(seen_.begin(), seen_.end());
     }
 
 private:
-    mutable std::mutex mutex_;
-    std::set<std::thread::id> ids_;
+    mutable std::mutex lock_;
+    std::vector<std::thread::id> seen_;
 };
+
+}  // namespace LAC

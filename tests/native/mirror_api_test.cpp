@@ -36,10 +36,10 @@ int main() {
     enc.set_zero_run_enabled(true);
     enc.set_partitioning_enabled(true);
     enc.set_thread_count(2);
-    ThreadCollector tc;
+    LAC::ThreadCollector tc;
     const std::vector<uint8_t> bytes = enc.encode(left, right, &tc);
     CHECK(bytes.size() > 22 && bytes[0] == 0x4C && bytes[1] == 0x41 && bytes[2] == 3);
-    CHECK(tc.count() == 1);
+    CHECK(tc.snapshot().size() == 1);
     Block::Encoder benc(12);
     benc.set_zero_run_enabled(false);
     benc.set_partitioning_enabled(false);
