@@ -207,7 +207,7 @@ struct Smem {
     } xp;
     uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
-    uint32_t tabF[G::T + 1];  // in: packed chunk flag counts; after scan: exclusive prefix
+    uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
@@ -582,6 +582,16 @@ LACX_HD uint32_t peek_u(const M& sh, uint32_t j, uint32_t limit) {
     return (j < limit) ? v : 1u;
 }
 
+// Packed flag counts (q > 3 in bits 0..15, q == 0 in bits 16..31) over the 96 samples that precede chunk t:
+// the sum of the W96 chunk counts before it (fewer at the start of the slot).
+template <class G>
+LACX_HD uint32_t window_flags(const uint32_t* tabF, int t) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 1; k <= G::W96; ++k) d += (t >= k) ? tabF[t - k] : 0u;
+    return d;
+}
+
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
 // (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
 template <class G, bool NARROW, bool ZR = true>
@@ -590,8 +600,9 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     const uint32_t n = th.n;
     uint64_t P = sh.tabP[t];                                   // P_{a-1}
     uint64_t W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;    // P_{a-1-256}
-    uint32_t F = sh.tabF[t];                                   // flag counts over [0, a-1]
-    uint32_t F96 = (t >= G::W96) ? sh.tabF[t - G::W96] : 0;    // ... over [0, a-1-96]
+    // packed flag counts over the 96 samples before the chunk = its W96 predecessors' chunk counts (the window
+    // starts on a chunk boundary); kept up to date sample by sample below
+    uint32_t D = window_flags<G>(sh.tabF, t);
     const uint32_t m256 = (t >= G::W256) ? 0x3FFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
     const uint32_t m96 = (t >= G::W96) ? 0xFFFFFFFFu : 0u;
     const int t256 = (t >= G::W256) ? t - G::W256 : t;
@@ -599,7 +610,7 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     uint32_t c = (uint32_t)th.a;
     // k in force for the first sample of the chunk: the value returned after sample a-1
     uint32_t kin = k0;
-    if (th.a > 0 && th.cnt > 0) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+    if (th.a > 0 && th.cnt > 0) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
     int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
     unsigned long long rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
@@ -629,10 +640,10 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         P += u;
         ++c;
         W += sh.u[i * G::T + t256] & m256;
-        F += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
         const uint32_t w96 = sh.u[i * G::T + t96] & m96;
-        F96 += ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
-        kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+        D += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);       // sample j enters the window ...
+        D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);     // ... sample j-96 leaves it
+        kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
         // slide the lookahead window
         w0 = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
         if (ZR) {

@@ -30,7 +30,7 @@ struct EmitMem {
     uint64_t tabP[G::T + 1];  // chunk sums -> exclusive prefix; later: bit counts -> bit offsets
     int32_t tabNZ[G::T + 1];  // last non-zero index -> exclusive prefix max
     int32_t tabNX[G::T + 1];  // first non-zero index -> exclusive suffix min (n if none)
-    uint32_t tabF[G::T + 1];  // packed flag counts -> exclusive prefix
+    uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
     uint64_t wtotP[16];
     int32_t wtotZ[16];
     uint32_t wtotF[16];
@@ -200,7 +200,7 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile*
     // --- state for the Rice parameter (pass 1 only) ---
     uint64_t P = sh.tabP[t];
     uint64_t Pseg = 0, W = 0;
-    uint32_t F = 0, F96 = 0, kin = k0;
+    uint32_t D = 0, kin = k0;  // D: packed flag counts over the last 96 samples
     const bool stateful = (p == 0);
     const uint32_t m256 = (t >= G::W256) ? 0x3FFFFFFFu : 0u, m96 = (t >= G::W96) ? 0xFFFFFFFFu : 0u;
     const int t256 = (t >= G::W256) ? t - G::W256 : t, t96 = (t >= G::W96) ? t - G::W96 : t;
@@ -208,9 +208,8 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile*
     if (pass1) {
         if (stateful) {
             W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;
-            F = sh.tabF[t];
-            F96 = (t >= G::W96) ? sh.tabF[t - G::W96] : 0;
-            if (th.a > 0 && mode != 3u) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+            D = window_flags<G>(sh.tabF, t);
+            if (th.a > 0 && mode != 3u) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
         } else {
             const uint32_t cs = s / G::CH;
             Pseg = sh.tabP[cs];
@@ -313,10 +312,10 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile*
             ++c;
             if (stateful) {
                 W += sh.u[i * G::T + t256] & m256;
-                F += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
                 const uint32_t w96 = sh.u[i * G::T + t96] & m96;
-                F96 += ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
-                kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, F - F96, c);
+                D += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
+                D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
+                kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
             } else {
                 kin = kmean_t<NARROW>(P - Pseg, j + 1u - s);
             }

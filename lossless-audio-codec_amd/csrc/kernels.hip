@@ -162,24 +162,6 @@ __device__ __forceinline__ void scan_pz_part2(M& sh, int tid, const ScanRegs<G>&
     }
 }
 
-template <class G, class M>
-__device__ __forceinline__ uint32_t scan_f_part1(M& sh, int tid, uint32_t& own) {
-    const int lane = tid & 63, wave = tid >> 6;
-    own = sh.tabF[tid];
-    const uint32_t inc = wave_scan_add_u32(own);
-    if (lane == 63) sh.wtotF[wave] = inc;
-    return inc;
-}
-
-template <class G, class M>
-__device__ __forceinline__ void scan_f_part2(M& sh, int tid, uint32_t inc, uint32_t own) {
-    const int wave = tid >> 6;
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += sh.wtotF[w];
-    sh.tabF[tid] = base + inc - own;
-    if (tid == G::T - 1) sh.tabF[G::T] = base + inc;
-}
-
 // Per-plane population counts of the wave's bit-sliced chunk counters, via ballots.  Ballot masks and
 // their popcounts are wave-uniform, so the per-plane totals accumulate on the scalar unit; planes above
 // the highest set bit in the wave are skipped.  Lanes 0..29 then add their plane's count to the block totals.
@@ -659,7 +641,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         STAMP(6);
         __syncthreads();  // B2
         STAMP(7);
-        if (tid == (G::T > 64 ? 64 : 0)) sh.cur_k0 = initial_k_from_planes(pt256, n);  // read after B4
+        if (tid == (G::T > 64 ? 64 : 0)) sh.cur_k0 = initial_k_from_planes(pt256, n);  // read after B3
         const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
         if (prm.debug_skip & 2u) {
             sh.tabF[tid] = 0;
@@ -669,16 +651,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         } else {
             phase_a<G, false>(th, sh);
         }
-        if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B4
+        if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B3
         STAMP(8);
-        uint32_t fown;
-        const uint32_t finc = scan_f_part1<G>(sh, tid, fown);
-        STAMP(9);
-        __syncthreads();  // B3
+        __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own)
         STAMP(10);
-        scan_f_part2<G>(sh, tid, finc, fown);
-        __syncthreads();  // B4
-        STAMP(11);
         const uint32_t k0 = sh.cur_k0;
         if (prm.debug_skip & 4u) {
             th.crice = th.cbin = th.czr = 1;
@@ -1018,10 +994,6 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
         } else {
             phase_a<G, false>(th, sh);
         }
-        uint32_t fown;
-        const uint32_t finc = scan_f_part1<G>(sh, tid, fown);
-        __syncthreads();
-        scan_f_part2<G>(sh, tid, finc, fown);
         __syncthreads();
     }
     ESTAMP(4);

@@ -93,15 +93,6 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         for (int t = 0; t < G::T; ++t) {
             if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
         }
-        {
-            uint32_t run = 0;
-            for (int t = 0; t < G::T; ++t) {
-                const uint32_t v = sh.tabF[t];
-                sh.tabF[t] = run;
-                run += v;
-            }
-            sh.tabF[G::T] = run;
-        }
         sh.acc[0][0] = sh.acc[0][1] = sh.acc[0][2] = sh.acc[0][3] = 0;
         bool zr = false;
         for (int t = 0; t < G::T; ++t) zr = zr || th[t].has4 != 0;
@@ -222,12 +213,6 @@ int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t*
     if (sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3) {
         for (int t = 0; t < G::T; ++t) {
             if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
-        }
-        uint32_t run = 0;
-        for (int t = 0; t < G::T; ++t) {
-            const uint32_t v = sh.tabF[t];
-            sh.tabF[t] = run;
-            run += v;
         }
     }
     // ownership check of the token writer: a plainly stored word must be untouched before and never OR-ed after
