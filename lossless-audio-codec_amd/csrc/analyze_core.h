@@ -430,8 +430,9 @@ LACX_HD void plane_counts(const uint32_t* u, uint32_t* cs) {
 // Fixed differences are taken in wrapping 32-bit arithmetic: the true values fit int32 for
 // |x| <= 2^24, so the low 32 bits equal the reference's int64 results.
 // ---------------------------------------------------------------------------------------------
+// Part 1: the chunk's zigzag residual into registers, and the partial sums of the pruning bound.
 template <class G, class M>
-LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
+LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u /* CH */) {
     // x[a-12 .. a+CH): element `el` of chunk tid+co sits at row el, column tid+co of the transposed
     // image, i.e. at a compile-time offset from one base address (no per-candidate address arithmetic).
     int32_t xh[G::CH + 12];
@@ -446,7 +447,6 @@ LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
         xh[i] = (tt >= 0) ? col[el * G::T] : 0;
     }
     const int32_t* x = xh + 12;
-    uint32_t u[G::CH];
     if (cand <= 4) {
 #pragma unroll
         for (int i = 0; i < G::CH; ++i) {
@@ -484,24 +484,43 @@ LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
             u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
         }
     }
+    // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours
+    uint32_t clzsum = 0, nzero = 0, nfour = 0;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        if (i < th.cnt) {
+            clzsum += (uint32_t)clz32(u[i]);
+            nzero += 1u - (u[i] < 1u ? u[i] : 1u);           // 1 when u == 0
+            const uint32_t x4 = u[i] ^ 4u;
+            nfour += 1u - (x4 < 1u ? x4 : 1u);               // 1 when u == 4
+        }
+    }
+    th.lb_g = 33u * (uint32_t)th.cnt - clzsum;
+    th.lb_aux = nzero + (nfour << 16);
+}
+
+// Part 2 (only for candidates that survive the pruning): the residual into LDS, the chunk sum, the last non-zero
+// index and the bit-sliced plane counts.
+template <class G, class M>
+LACX_HD void phase_r_store(Thread<G>& th, M& sh, const uint32_t* u) {
     uint64_t s = 0;
     int32_t lastnz = -1;
-    uint32_t lbg = 0, lbaux = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         s += u[i];
         if (u[i] != 0) lastnz = th.a + i;
         sh.u[i * G::T + th.tid] = u[i];
-        if (i < th.cnt) {
-            lbg += (uint32_t)(32 - clz32(u[i])) + 1u;
-            lbaux += (u[i] == 0u ? 1u : 0u) + (u[i] == 4u ? 0x10000u : 0u);
-        }
     }
-    th.lb_g = lbg;
-    th.lb_aux = lbaux;
     sh.tabP[th.tid] = s;
     sh.tabNZ[th.tid] = lastnz;
     plane_counts<G>(u, th.cs);
+}
+
+template <class G, class M>
+LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
+    uint32_t u[G::CH];
+    phase_r_residual(th, sh, cand, u);
+    phase_r_store(th, sh, u);
 }
 
 // Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.

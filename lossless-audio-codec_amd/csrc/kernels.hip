@@ -613,11 +613,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             pending = -1;
         }
         STAMP(1);
-        phase_r(th, sh, cand);
+        uint32_t ures[G::CH];
+        phase_r_residual(th, sh, cand, ures);
         STAMP(2);
-        ScanRegs<G> sr;
-        scan_pz_part1(sh, tid, sr);
-        STAMP(3);
         {
             // block sums for the pruning bound
             const uint32_t g = wave_sum_u32(th.lb_g), a = wave_sum_u32(th.lb_aux);
@@ -630,12 +628,17 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         __syncthreads();  // B1
         STAMP(5);
         // Exact pruning: the previous candidates are scored (thread 0 did it before this barrier), so
-        // sh.best_bits is final for them; a candidate that cannot beat it stops here, before the plane
-        // counts and the adaptive passes (its reduction buffers are untouched, so nothing needs clearing).
+        // sh.best_bits is final for them; a candidate that cannot beat it stops here -- its residual never left
+        // the registers, no plane counts, no scans, no adaptive passes (and nothing to clear).
         if (!(prm.debug_skip & 128u) &&
             candidate_pruned(candidate_lower_bound(sh.lbacc[cand][0], sh.lbacc[cand][1], n, prm.zero_run), cand,
                              sh.best_bits, sh.best_cand))
             continue;
+        phase_r_store(th, sh, ures);
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        STAMP(3);
+        __syncthreads();  // B1b: the wave totals of the scan
         scan_pz_part2(sh, tid, sr);
         if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
         STAMP(6);
