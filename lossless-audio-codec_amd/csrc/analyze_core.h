@@ -25,6 +25,8 @@
 // tests (tests/native/sim_analyze.cpp).  Cross-thread steps (block scans, ballots, LDS atomics) live in
 // the drivers.
 #pragma once
+#include <type_traits>
+
 #include "lacx_types.h"
 #include "x87.h"
 
@@ -448,19 +450,27 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
     }
     const int32_t* x = xh + 12;
     if (cand <= 4) {
+        // one loop per order (block-uniform branch) rather than all four formulas plus selects per sample
+        auto fixed = [&](auto order_tag) {
+            constexpr int K = decltype(order_tag)::value;
 #pragma unroll
-        for (int i = 0; i < G::CH; ++i) {
-            const int j = th.a + i;
-            const uint32_t x0 = (uint32_t)x[i], x1 = (uint32_t)x[i - 1], x2 = (uint32_t)x[i - 2],
-                           x3 = (uint32_t)x[i - 3], x4 = (uint32_t)x[i - 4];
-            uint32_t r = x0;
-            if (cand == 1) r = x0 - x1;
-            if (cand == 2) r = x0 - 2u * x1 + x2;
-            if (cand == 3) r = x0 - 3u * x1 + 3u * x2 - x3;
-            if (cand == 4) r = x0 - 4u * x1 + 6u * x2 - 4u * x3 + x4;
-            if (j < cand) r = x0;  // warm-up samples are stored raw
-            u[i] = (i < th.cnt) ? zigzag32((int32_t)r) : 0u;
-        }
+            for (int i = 0; i < G::CH; ++i) {
+                const uint32_t x0 = (uint32_t)x[i], x1 = (uint32_t)x[i - 1], x2 = (uint32_t)x[i - 2],
+                               x3 = (uint32_t)x[i - 3], x4 = (uint32_t)x[i - 4];
+                uint32_t r = x0;
+                if (K == 1) r = x0 - x1;
+                if (K == 2) r = x0 - 2u * x1 + x2;
+                if (K == 3) r = x0 - 3u * x1 + 3u * x2 - x3;
+                if (K == 4) r = x0 - 4u * x1 + 6u * x2 - 4u * x3 + x4;
+                if (K > 0 && th.a + i < K) r = x0;  // warm-up samples are stored raw
+                u[i] = (i < th.cnt) ? zigzag32((int32_t)r) : 0u;
+            }
+        };
+        if (cand == 0) fixed(std::integral_constant<int, 0>{});
+        else if (cand == 1) fixed(std::integral_constant<int, 1>{});
+        else if (cand == 2) fixed(std::integral_constant<int, 2>{});
+        else if (cand == 3) fixed(std::integral_constant<int, 3>{});
+        else fixed(std::integral_constant<int, 4>{});
     } else if (cand == 5) {
 #pragma unroll
         for (int i = 0; i < G::CH; ++i) {
