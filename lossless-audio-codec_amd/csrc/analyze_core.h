@@ -480,19 +480,28 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
             u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
         }
     } else {
+        // one loop per tap count (block-uniform branch): an order-4 candidate multiplies 4 taps, not 12
         const int ci = cand - 6;
         const int ord = sh.lpc.used[ci];
-        int32_t c[13];
+        auto lpc = [&](auto taps_tag) {
+            constexpr int TAPS = decltype(taps_tag)::value;
+            int32_t c[TAPS + 1];
 #pragma unroll
-        for (int t = 1; t <= 12; ++t) c[t] = (t <= ord) ? (int32_t)sh.lpc.coef[ci][t] : 0;
+            for (int t = 1; t <= TAPS; ++t) c[t] = (t <= ord) ? (int32_t)sh.lpc.coef[ci][t] : 0;
 #pragma unroll
-        for (int i = 0; i < G::CH; ++i) {
-            int64_t acc = 0;
+            for (int i = 0; i < G::CH; ++i) {
+                int64_t acc = 0;
 #pragma unroll
-            for (int t = 1; t <= 12; ++t) acc += (int64_t)c[t] * (int64_t)x[i - t];
-            const int32_t r = (int32_t)((int64_t)x[i] - (acc >> 15));
-            u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
-        }
+                for (int t = 1; t <= TAPS; ++t) acc += (int64_t)c[t] * (int64_t)x[i - t];
+                const int32_t r = (int32_t)((int64_t)x[i] - (acc >> 15));
+                u[i] = (i < th.cnt) ? zigzag32(r) : 0u;
+            }
+        };
+        if (ord <= 4) lpc(std::integral_constant<int, 4>{});
+        else if (ord <= 6) lpc(std::integral_constant<int, 6>{});
+        else if (ord <= 8) lpc(std::integral_constant<int, 8>{});
+        else if (ord <= 10) lpc(std::integral_constant<int, 10>{});
+        else lpc(std::integral_constant<int, 12>{});
     }
     // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours
     uint32_t clzsum = 0, nzero = 0, nfour = 0;
