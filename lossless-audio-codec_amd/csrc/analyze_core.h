@@ -503,19 +503,20 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
         else if (ord <= 10) lpc(std::integral_constant<int, 10>{});
         else lpc(std::integral_constant<int, 12>{});
     }
-    // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours
+    // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours.
+    // Positions beyond the slot hold u = 0: they are summed like the others (no per-sample predicate) and taken
+    // out afterwards: each adds 32 to the leading-zero sum and 1 to the zero count.
     uint32_t clzsum = 0, nzero = 0, nfour = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
-        if (i < th.cnt) {
-            clzsum += (uint32_t)clz32(u[i]);
-            nzero += 1u - (u[i] < 1u ? u[i] : 1u);           // 1 when u == 0
-            const uint32_t x4 = u[i] ^ 4u;
-            nfour += 1u - (x4 < 1u ? x4 : 1u);               // 1 when u == 4
-        }
+        clzsum += (uint32_t)clz32(u[i]);
+        nzero += 1u - (u[i] < 1u ? u[i] : 1u);           // 1 when u == 0
+        const uint32_t x4 = u[i] ^ 4u;
+        nfour += 1u - (x4 < 1u ? x4 : 1u);               // 1 when u == 4
     }
-    th.lb_g = 33u * (uint32_t)th.cnt - clzsum;
-    th.lb_aux = nzero + (nfour << 16);
+    const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
+    th.lb_g = 33u * (uint32_t)th.cnt - (clzsum - 32u * beyond);
+    th.lb_aux = (nzero - beyond) + (nfour << 16);
 }
 
 // Part 2 (only for candidates that survive the pruning): the residual into LDS, the chunk sum, the last non-zero
