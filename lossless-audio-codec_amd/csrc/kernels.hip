@@ -176,13 +176,14 @@ __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t*
     // lanes of wave 0 whose chunk lies inside the first 256 samples
     const uint64_t m256 = (G::W256 >= 64) ? ~0ull : ((1ull << (G::W256 & 63)) - 1ull);
     uint32_t mine = 0, mine256 = 0;
+    const bool first256 = wave == 0;  // only wave 0 holds samples of the first 256 (uniform)
     for (int b = 0; b < nplanes; ++b) {
         uint32_t tot = 0, tot256 = 0;
 #pragma unroll
         for (int l = 0; l < G::LV; ++l) {
             const uint64_t m = __ballot((th.cs[l] >> b) & 1u);
             tot += (uint32_t)__popcll(m) << l;
-            tot256 += (uint32_t)__popcll(m & m256) << l;
+            if (first256) tot256 += (uint32_t)__popcll(m & m256) << l;
         }
         if (lane == b) {
             mine = tot;

@@ -15,7 +15,7 @@ buf = (C.c_ulonglong * 32)()
 for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
     enc.analyze_device(dl.data_ptr(), dr.data_ptr(), L.size, 0)
     lib.lacx_debug_stamps(buf)
-names = ["stage", "score(prev)", "phase_r", "scan1", "lb reduce", "B1 wait", "scan2+planes", "B2 wait", "phase_a", "scanF1", "B3 wait", "scanF2+B4", "phase_b", "reduce", "B5 wait", "final score", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final"]
+names = ["stage", "score(prev)", "residual+bound", "store+scan1", "bound reduce", "B1 wait", "scan2+planes", "B2 wait", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "final score", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final"]
 tot = sum(buf[i] for i in range(22))
 waves = buf[24]
 print(f"waves {waves}, cycles/wave {tot / max(1, waves):.0f}, full_ms {enc.timing().full_ms:.3f}, realtime ticks/wave {buf[22] / max(1, waves):.0f} -> shader clock {tot / max(1, buf[22]) * 0.1:.3f} GHz, wave lifetime {buf[22] / max(1, waves) / 100:.1f} us")
