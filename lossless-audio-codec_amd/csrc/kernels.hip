@@ -777,7 +777,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, plan_out);
     STAMP(21);
 #if defined(LACX_STAMPS) && LACX_STAMPS == 1
-    if ((tid & 63) == 0 && G::T == 1024) {
+    // one wave per workgroup reports (a different one from workgroup to workgroup): with every wave adding its 24
+    // sums to the same addresses the atomics themselves slowed every global load in the kernel down severalfold
+    if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u) && G::T == 1024) {
         stamp_acc[22] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
         for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
         atomicAdd(&g_stamp_acc[24], 1ull);
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
         ESTAMP(12);
     }
 #if defined(LACX_STAMPS) && LACX_STAMPS == 2
-    if ((tid & 63) == 0) {
+    if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u)) {  // one wave per workgroup, see k_analyze
         estamp_acc[22] = __builtin_amdgcn_s_memrealtime() - estamp_rt0;
         for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], estamp_acc[k]);
         atomicAdd(&g_stamp_acc[24], 1ull);

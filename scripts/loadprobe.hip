@@ -10,6 +10,7 @@ __global__ __launch_bounds__(1024) void k_probe(const uint4* __restrict__ in, ui
     if (threadIdx.x == 0) lds[0] = 1;
     int spin = spin0;
     if (jitter) spin = (int)(spin0 * (0.5f + (float)((blockIdx.x * 2654435761u) >> 24) / 256.0f));
+    if (heavy) __syncthreads();  // all 16 waves issue their loads at the same moment
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned g = blockIdx.x / 16u, r = blockIdx.x % 16u;
     const unsigned region = pair ? (g * 8u + (r & 7u)) : blockIdx.x;  // pair: workgroups w and w+8 read the same 64 KB
@@ -50,8 +51,8 @@ int main() {
         const int spin = 400000;
         const int jitter = cfg & 1;
         const int pair = 0;
-        const int heavy = 0;
-        const int tail = cfg >> 1;
+        const int heavy = cfg >> 1;
+        const int tail = 0;
         const int ldsb = 120 * 1024;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipMemset(acc, 0, 16));
