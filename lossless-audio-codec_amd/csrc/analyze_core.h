@@ -946,7 +946,11 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     uint32_t P = Pa;
     uint32_t u = sh.u[t];
     uint32_t x1 = peek_u<G>(sh, a + 1u, n), x2 = peek_u<G>(sh, a + 2u, n), x3 = peek_u<G>(sh, a + 3u, n);
-    for (int i = 0; i < th.cnt; ++i) {
+    // One sample of the chunk for every order.  FIRST: the chunk's first sample, the only one that can be the first
+    // of a partition (partitions start on chunk boundaries here) and then takes the partition's initial k.
+    // kin <= 31 throughout (sums < 2^31, see kmean32) and u < 2^31, so u >> kin needs no k >= 31 special case.
+    auto sample = [&](int i, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const uint32_t j = a + (uint32_t)i;
         const bool z = (u == 0);
         fg = z ? fg + 1 : 0;
@@ -957,8 +961,9 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         for (int q = 0; q < G::MAXP; ++q) {
             if (q < max_p) {
                 const uint32_t cbefore = j - s[q];                       // samples of the partition before j
-                const uint32_t kin = (cbefore == 0) ? ak[q] : kmean32(P - Pseg[q], cbefore);
-                const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
+                uint32_t kin = kmean32(P - Pseg[q], FIRST ? (cbefore ? cbefore : 1u) : cbefore);
+                if (FIRST) kin = (cbefore == 0) ? ak[q] : kin;
+                const uint32_t rc = (u >> kin) + 1u + kin;
                 rice[q] += rc;
                 bin[q] += is_small ? small : 2u + rc;
                 if (ZR) {
@@ -980,7 +985,9 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         x1 = x2;
         x2 = x3;
         x3 = peek_u<G>(sh, j + 4u, n);
-    }
+    };
+    sample(0, std::true_type{});
+    for (int i = 1; i < th.cnt; ++i) sample(i, std::false_type{});
 #pragma unroll
     for (int q = 0; q < G::MAXP; ++q) {
         if (q < max_p) flush(sidx[q], rice[q], bin[q], zr[q], (hasrun >> q) & 1u);
