@@ -651,7 +651,9 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     uint32_t kin = k0;
     if (th.a > 0 && th.cnt > 0) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
     int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
-    unsigned long long rice = 0, bin = 0, zr = 0;
+    // chunk sums: 32 bits suffice on the narrow path (each cost <= u + 34 and the block's sum of u is < 2^31)
+    using Acc = typename std::conditional<NARROW, uint32_t, unsigned long long>::type;
+    Acc rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
     uint32_t w0 = sh.u[t];  // own sample incl. flags
     uint32_t n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n), n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n),
@@ -660,7 +662,7 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     for (int i = 0; i < G::CH; ++i) {
         if (i >= th.cnt) break;
         const uint32_t u = w0 & 0x3FFFFFFFu;
-        const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
+        const uint32_t rc = (u >> kin) + 1u + kin;  // kin <= 31 (biased_k clamps) and u < 2^30: no k >= 31 special case
         rice += rc;
         bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
         if (ZR) {
