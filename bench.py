@@ -109,8 +109,8 @@ def main():
 
     def exchange(table):
         if world > 1:
-            sizes = torch.from_numpy(table[:, 1].astype(np.int64)).cuda()
-            mine = torch.tensor([int(sizes.sum().item()), table.shape[0]], dtype=torch.int64, device="cuda")
+            # the block table is already on the host: sum it there, exchange two integers per rank
+            mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device="cuda")
             allv = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
 
