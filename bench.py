@@ -59,6 +59,11 @@ def main():
     BIT_DEPTH, SAMPLE_RATE = args.bit_depth, args.rate  # locals shadowing the defaults from here on
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank uses GPU 0 and the exchange
+    # runs over gloo on host tensors, because RCCL refuses two ranks on one device.
+    rehearse = os.environ.get("LACX_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -69,7 +74,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    xdev = "cpu" if rehearse else "cuda"
 
     pkg = ge.load_pkg()
     lacx, synth = pkg.lacx, pkg.synth
@@ -110,7 +119,7 @@ def main():
     def exchange(table):
         if world > 1:
             # the block table is already on the host: sum it there, exchange two integers per rank
-            mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device="cuda")
+            mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device=xdev)
             allv = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
 
@@ -169,7 +178,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = enc.timing()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
