@@ -12,6 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -341,3 +342,29 @@ def test_begin_end_interface(gpu, oracle):
         assert gpu.lacx.assemble(sr, bd, sm, 2, [(p, t)]) == oracle.encode(left, right, sr, bd, sm, threads=8)
     with pytest.raises(RuntimeError, match="no encode in flight"):
         encs[0].encode_shard_end()
+
+
+def test_cli_encode_command(gpu, oracle, tmp_path):
+    """lacx_cli encode: the reference CLI's encode command (ref src/main.cpp:609-710) over the C ABI."""
+    import subprocess
+
+    import wavutil as W
+
+    pkg_dir = os.path.join(ROOT, "lossless-audio-codec_amd")
+    subprocess.check_call(["make", "-C", pkg_dir, "lacx_cli"], stdout=subprocess.DEVNULL)
+    cli = os.path.join(pkg_dir, "lacx_cli")
+    left, right = gpu.synth.synth_pcm(16384 * 2 + 4321, 2, 24, 96000, seed=51, kind="mixed")
+    wav = tmp_path / "in.wav"
+    wav.write_bytes(W.make_wav(left, right, 96000, 24, before=[W.chunk(b"LIST", b"abc")]))
+    for flags, sm, part in (([], 2, True), (["--stereo-mode=ms", "--threads=3"], 1, True), (["--no-partitioning", "--stereo-mode=lr"], 0, False)):
+        out = tmp_path / "out.lac"
+        res = subprocess.run([cli, "encode", str(wav), str(out)] + flags, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        want = oracle.encode(left, right, 96000, 24, sm, partitioning=part, threads=8)
+        assert out.read_bytes() == want
+        assert f"({len(want)} bytes)" in res.stdout
+    bad = subprocess.run([cli, "encode", str(wav), str(tmp_path / "x.lac"), "--threads=0"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "--threads requires a positive integer" in bad.stderr
+    bad = subprocess.run([cli, "encode", str(tmp_path / "missing.wav"), str(tmp_path / "x.lac")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Failed to read WAV" in bad.stderr
+    assert subprocess.run([cli, "encode", str(wav), str(wav)], capture_output=True).returncode == 1
