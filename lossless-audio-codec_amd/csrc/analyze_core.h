@@ -658,7 +658,7 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     uint32_t w0 = sh.u[t];  // own sample incl. flags
     uint32_t n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n), n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n),
              n3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
-#pragma unroll
+#pragma nounroll  // one sample per trip: the 16-fold body does not fit the register budget
     for (int i = 0; i < G::CH; ++i) {
         if (i >= th.cnt) break;
         const uint32_t u = w0 & 0x3FFFFFFFu;
