@@ -104,6 +104,27 @@ int hip_fail(lacx_encoder* e, hipError_t err, const char* what) {
         if (_err != hipSuccess) return hip_fail(e, _err, what); \
     } while (0)
 
+// Copy of a large result out of the pinned buffer: split over a few threads (a single memcpy into freshly allocated
+// memory runs at page-fault speed; the tens of MB of a payload took longer than the whole device encode).
+void big_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    constexpr uint64_t kPiece = 4ull << 20;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint64_t want = std::min<uint64_t>(std::min<uint64_t>(8, hw ? hw : 1), n / kPiece);
+    if (want < 2) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n / want + 4095) & ~4095ull;
+    for (uint64_t t = 1; t < want; ++t) {
+        const uint64_t o = t * per;
+        if (o >= n) break;
+        pool.emplace_back([=] { std::memcpy(dst + o, src + o, std::min(per, n - o)); });
+    }
+    std::memcpy(dst, src, std::min(per, n));
+    for (auto& th : pool) th.join();
+}
+
 int ensure_device(lacx_encoder* e) {
     if (e->device_ready) return LACX_OK;
     int count = 0;
@@ -898,7 +919,7 @@ int lacx_encode_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_
                 put32(buf + 14 + 8ull * b, e->h_table[2 * b]);
                 put32(buf + 18 + 8ull * b, e->h_table[2 * b + 1]);
             }
-            std::memcpy(buf + head, e->h_payload, pay);
+            big_copy(buf + head, e->h_payload, pay);
             *out = buf;
             *out_size = head + pay;
             e->timing.total_ms = ms_since(t0);
@@ -1079,7 +1100,7 @@ int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32
         std::free(tab);
         return fail(e, LACX_E_RUNTIME, "out of memory");
     }
-    std::memcpy(buf, vp, pay);
+    big_copy(buf, vp, pay);
     std::memcpy(tab, vt, sizeof(uint32_t) * 2 * nb);
     *payload = buf;
     *payload_size = pay;
@@ -1175,7 +1196,7 @@ int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const 
             put32(buf + 14 + 8 * bi, tables[s][2 * b]);
             put32(buf + 18 + 8 * bi, tables[s][2 * b + 1]);
         }
-        std::memcpy(buf + off, payloads[s], payload_sizes[s]);
+        big_copy(buf + off, payloads[s], payload_sizes[s]);
         off += payload_sizes[s];
     }
     *out = buf;

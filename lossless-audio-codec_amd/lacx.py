@@ -340,8 +340,9 @@ class Encoder:
         out = C.POINTER(C.c_uint8)()
         size = C.c_uint64()
         h = self._handle()
-        buf = (C.c_uint8 * len(wav)).from_buffer_copy(wav)
-        rc = lib().lacx_encode_wav(h, buf, C.c_uint64(len(wav)), C.byref(out), C.byref(size))
+        view = np.frombuffer(wav, dtype=np.uint8)  # no copy: the library only reads the image
+        rc = lib().lacx_encode_wav(h, view.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(view.size), C.byref(out),
+                                   C.byref(size))
         if rc != OK:
             _raise(h, rc)
         try:

@@ -1,0 +1,21 @@
+"""Diagnostic: whole-call rates with the PCM starting in host memory (never the bench's `value`)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import __graft_entry__ as ge
+import wavutil as W
+pkg = ge.load_pkg(); lacx, synth = pkg.lacx, pkg.synth
+frames = 28_800_000
+L, R = synth.synth_pcm(frames, 2, 16, 48000, seed=2026, kind="music")
+enc = lacx.Encoder(12, 2, 48000, 16)
+wav = W.make_wav(L, R, 48000, 16)
+for name, fn in (("lacx_encode (planar int32 host PCM, 230 MB H2D)", lambda: enc.encode(L, R)),
+                 ("lacx_encode_wav (WAV image in host memory, 115 MB H2D)", lambda: enc.encode_wav(wav))):
+    fn()
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter(); out = fn(); best = min(best, time.perf_counter() - t0)
+    t = enc.timing()
+    print(f"{name}: {best * 1e3:.1f} ms from Python (incl. the bytes copy of the result) -> {frames * 2 / best / 1e6:.0f} Msamples/s; "
+          f"inside the library {t.total_ms:.1f} ms of which H2D {t.h2d_ms:.1f} ms ({len(out)} B)")
