@@ -392,17 +392,25 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
                 for (int k = 0; k < 13; ++k) acc[k] += (int64_t)w[12 + i] * (int64_t)w[12 + i - k];
             }
             if (est) {
+                // 32-bit zigzags and per-tile 32-bit partial sums: for samples inside the validated range
+                // |x| <= 2^24 (mid/side included) the differences fit 26 bits and 16 of them 30; out-of-range
+                // input only garbles an estimate of a stream that is rejected anyway.
+                auto zz32 = [](int32_t v) { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); };
+                uint32_t traw = 0, tdif = 0, tant = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (i < cnt) {
-                        const int64_t x0 = w[12 + i], prev = w[11 + i];
-                        const uint64_t raw = zz64(x0);
+                        const int32_t x0 = w[12 + i], prev = w[11 + i];
+                        const uint32_t raw = zz32(x0);
                         const bool head = (first + (uint32_t)i) == 0u;
-                        sraw += raw;
-                        sdif += head ? raw : zz64(x0 - prev);
-                        sant += head ? raw : zz64(x0 + prev);
+                        traw += raw;
+                        tdif += head ? raw : zz32((int32_t)((uint32_t)x0 - (uint32_t)prev));
+                        tant += head ? raw : zz32((int32_t)((uint32_t)x0 + (uint32_t)prev));
                     }
                 }
+                sraw += traw;
+                sdif += tdif;
+                sant += tant;
             }
         }
         __syncthreads();
