@@ -232,7 +232,7 @@ def main():
 
     # ---- CPU baseline: the unmodified reference (oracle/_ref) on this box's host cores ----------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
         cores = emit_threads  # same CPU share as the GPU path's host emit
         try:
             import refshim
@@ -240,8 +240,8 @@ def main():
             have_ref = refshim.available()
         except Exception:
             have_ref = False
-        # bounded sample: the first `n_cpu` frames of the same stream (all of it if that is quick)
-        n_cpu = min(frames, 12_000_000)
+        # bounded sample: the same stream, at most the whole 10-minute config (about 20 s of CPU work over the threads)
+        n_cpu = min(frames, 28_800_000)
         t1 = time.perf_counter()
         if have_ref:
             data = refshim.encode(left[:n_cpu], right[:n_cpu], SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, threads=cores)
