@@ -232,6 +232,7 @@ def main():
 
     # ---- CPU baseline: the unmodified reference (oracle/_ref) on this box's host cores ----------
     cpu = None
+    identical = None  # set when the CPU leg encoded the whole stream: GPU bytes == CPU bytes
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
         cores = emit_threads  # same CPU share as the GPU path's host emit
         try:
@@ -252,6 +253,12 @@ def main():
             data = oracleshim.encode(left[:n_cpu], right[:n_cpu], SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, threads=cores)
             kind = "port"
         dt = time.perf_counter() - t1
+        # outside every timed region: the last timed step's GPU output against the CPU encoder's, byte for byte
+        if last is not None and n_cpu == frames:
+            gpu_lac = lacx.assemble(SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, 2, [(last[0].tobytes(), last[1].copy())])
+            identical = gpu_lac == data
+            if not identical:
+                raise SystemExit("bench.py: the GPU .lac differs from the CPU encoder's -- refusing to report a number")
         cpu = {
             "value": round(n_cpu * 2 / dt / 1e6, 3),
             "unit": "Msamples/s",
@@ -298,6 +305,7 @@ def main():
         "device_analysis_msamples_s": round(frames * 2 / (float(np.mean(analysis_ms)) / 1e3) / 1e6, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "byte_identical_to_cpu_baseline": identical,
     }
     print(json.dumps(out))
     if world > 1:
