@@ -5,71 +5,130 @@ A "step" is one whole-job encode of the rank's shard with the PCM already reside
 layout (interleaved int16, the WAV data chunk): ingest + Levinson + probe/whole-block analysis kernels,
 device-side bit emit straight into pinned host memory, block table D2H -> shard payload + block table on the
 host.  For N > 1 the ranks then all_gather (payload bytes, block count) over RCCL -- the path's only exchange
-step -- so every rank knows its byte offset in the final .lac.  Workload at N=1 = BASELINE configs[1]: 10 min
-synthetic stereo 16-bit 48 kHz, per-block auto MS/LR, LPC search, default 16384-frame blocks; with N ranks
-the stream is N x 10 min and rank r takes the r-th contiguous block range (weak scaling).
+step -- so every rank knows its byte offset in the final .lac.
+
+Workloads:
+  N = 1   BASELINE configs[1]: 10 min synthetic stereo 16-bit 48 kHz, per-block auto MS/LR, LPC search, 16384-frame
+          blocks.  The last timed step's .lac is compared byte for byte with the CPU reference's and with the golden
+          digest.
+  N > 1   BASELINE configs[3]: ONE 2 h stereo 16/48 stream (345 600 000 frames, 21 094 blocks); rank r encodes blocks
+          [r*B/N, (r+1)*B/N) (strong split of a fixed stream, no data-path collective).  After the timed loop every
+          rank checks each eighth of its shard against the golden digests minted from the reference
+          (tests/golden/digests.json, cfg4_2h_shard{1..8}of8) -> "byte_identical_shards": "N/N".  The same ranks then
+          also time the weak line (10 min per GPU) -> "weak_10min_per_gpu".
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, started before this process touches any GPU), relays rank 0's JSON line and exits
+non-zero when a rank fails.  With fewer visible GPUs than ranks the ranks share the GPUs and exchange over gloo: a
+rehearsal of the code path ("rehearsal_shared_gpu": true), not a measurement.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import __graft_entry__ as ge  # noqa: E402
-
-SAMPLE_RATE = 48000
-BIT_DEPTH = 16
 STEREO_MODE = 2
-SECONDS = 600
 BLOCK = 16384
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz: one wave64 VALU instruction = 2 cycles
+CFG2_SECONDS = 600
+CFG4_SECONDS = 7200
+METRIC = "encode Msamples/s at 1/2/4/8 MI355X; byte-identical .lac vs CPU ref"
 
 
-def main():
-    global BIT_DEPTH, SAMPLE_RATE
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=int, default=SECONDS, help="audio seconds per GPU (default: the 10 min config)")
+    ap.add_argument("--workload", default="auto", choices=("auto", "cfg2", "cfg4"),
+                    help="auto: configs[1] (10 min per GPU) at N=1, configs[3] (one 2 h stream, block-range split) at N>1")
+    ap.add_argument("--seconds", type=int, default=0, help="diagnostic: audio seconds per GPU instead of the named config")
     ap.add_argument("--kind", default="music")
-    ap.add_argument("--bit-depth", type=int, default=BIT_DEPTH, choices=(16, 24), help="diagnostic: other BASELINE configs")
-    ap.add_argument("--rate", type=int, default=SAMPLE_RATE, choices=(44100, 48000, 96000, 192000))
+    ap.add_argument("--bit-depth", type=int, default=16, choices=(16, 24), help="diagnostic: other BASELINE configs")
+    ap.add_argument("--rate", type=int, default=48000, choices=(44100, 48000, 96000, 192000))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak-line", action="store_true", help="N>1: skip the additional 10 min per GPU measurement")
+    ap.add_argument("--no-end-to-end", action="store_true", help="N=1: skip the host WAV -> host .lac measurement")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
-    ap.add_argument("--inflight", type=int, default=1, choices=(1, 2),
-                    help="diagnostic: 2 = the next step is enqueued on a second encoder before the previous step's result "
-                         "is collected (measured slower: the two encodes' kernels time-slice the CUs)")
     ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher: no GPU call may happen in this process
+# ---------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})\n")
+        sys.stderr.write(proc.stdout[-4000:])
+        return proc.returncode or 1
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished without a JSON line\n" + proc.stdout[-4000:])
+        return 1
+    print(line)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------
+def load_digests():
+    with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+        return {d["name"]: d for d in json.load(f)}
+
+
+def worker(args) -> int:
+    import numpy as np
     import torch
 
-    BIT_DEPTH, SAMPLE_RATE = args.bit_depth, args.rate  # locals shadowing the defaults from here on
+    import __graft_entry__ as ge
+
+    bit_depth, sample_rate = args.bit_depth, args.rate
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal of the N > 1 code path on a one-GPU box (not a measurement): every rank uses GPU 0 and the exchange
-    # runs over gloo on host tensors, because RCCL refuses two ranks on one device.
-    rehearse = os.environ.get("LACX_BENCH_REHEARSE_ON_ONE_GPU") == "1"
-    if rehearse:
-        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()  # does not initialise a device
+    if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (the LAC analysis path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # Fewer GPUs than ranks (the one-GPU development box): ranks share the GPUs and exchange over gloo, because RCCL
+    # refuses two ranks on one device.  A rehearsal of the N > 1 code path, flagged as such in the output.
+    rehearse = os.environ.get("LACX_BENCH_REHEARSE_ON_ONE_GPU") == "1" or ndev < world
+    device = local_rank % ndev if rehearse else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -77,143 +136,193 @@ def main():
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
     xdev = "cpu" if rehearse else "cuda"
 
     pkg = ge.load_pkg()
     lacx, synth = pkg.lacx, pkg.synth
-
-    # ---- workload: contiguous block range of an (N x seconds) stream -------------------------
-    total_frames = args.seconds * SAMPLE_RATE * world
-    total_blocks = (total_frames + BLOCK - 1) // BLOCK
-    b0 = rank * total_blocks // world
-    b1 = (rank + 1) * total_blocks // world
-    f0 = b0 * BLOCK
-    f1 = min(b1 * BLOCK, total_frames)
-    frames = f1 - f0
-    left, right = synth.synth_pcm(frames, 2, BIT_DEPTH, SAMPLE_RATE, seed=2026, kind=args.kind, start=f0)
-    interleaved = not (args.planar or args.host_emit or args.analysis_only)
-    if interleaved:  # the WAV data-chunk layout: interleaved little-endian int16, 2 bytes per sample in HBM
-        inter = synth.interleave(left, right, BIT_DEPTH)
-        d_pcm = torch.from_numpy(inter.view(np.int16) if BIT_DEPTH == 16 else inter).cuda()
-    else:
-        d_left = torch.from_numpy(left).cuda()
-        d_right = torch.from_numpy(right).cuda()
-    torch.cuda.synchronize()
+    digests = load_digests()
 
     host_cores = os.cpu_count() or 1
-    # host emit workers: the box's CPU share per GPU (16), overridable for tuning
+    # host threads of this rank: the box's CPU share per GPU (16), overridable for tuning
     share = max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     emit_threads = int(os.environ.get("LACX_EMIT_THREADS", "0")) or min(16, share)
-    inflight = args.inflight if interleaved else 1
-    encs = []
-    for _ in range(inflight):
-        e_ = lacx.Encoder(12, STEREO_MODE, SAMPLE_RATE, BIT_DEPTH, device=local_rank)
-        e_.set_thread_count(emit_threads)
-        e_.set_host_emit(args.host_emit)
-        encs.append(e_)
-    enc = encs[0]
+    enc = lacx.Encoder(12, STEREO_MODE, sample_rate, bit_depth, device=device)
+    enc.set_thread_count(emit_threads)
+    enc.set_host_emit(args.host_emit)
     stream = torch.cuda.current_stream().cuda_stream
-    layout = lacx.PCM_INTERLEAVED_I16 if BIT_DEPTH == 16 else lacx.PCM_INTERLEAVED_I24
-
-    def exchange(table):
-        if world > 1:
-            # the block table is already on the host: sum it there, exchange two integers per rank
-            mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device=xdev)
-            allv = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
-
-    def begin(i):  # enqueue step i (returns at once on the interleaved device-emit path)
-        e_ = encs[i % inflight]
-        if args.analysis_only:
-            e_.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
-        elif interleaved:
-            e_.encode_shard_pcm_device_begin(d_pcm.data_ptr(), layout, 2, frames, stream)
-
-    def end(i):  # collect step i: payload + block table of the shard on the host
-        e_ = encs[i % inflight]
-        if args.analysis_only:
-            return None, e_.timing()
-        if interleaved:
-            payload, table = e_.encode_shard_end()
-        else:
-            payload, table = e_.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames, stream)
-        exchange(table)
-        return (payload, table), e_.timing()
-
-    def run(nsteps, record):
-        last_ = None
-        for i in range(nsteps):
-            begin(i)
-            if i >= inflight - 1:
-                last_, t = end(i - (inflight - 1))
-                record(t)
-        for j in range(max(0, nsteps - (inflight - 1)), nsteps):
-            last_, t = end(j)
-            record(t)
-        return last_
+    layout = lacx.PCM_INTERLEAVED_I16 if bit_depth == 16 else lacx.PCM_INTERLEAVED_I24
+    interleaved = not (args.planar or args.host_emit or args.analysis_only)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, lambda t: None)
-    sync()
-    full_ms, analysis_ms, emit_ms, probe_ms, ingest_ms, launches, api_ms, exec_ms = [], [], [], [], [], [], [], []
+    def all_sum(x: int) -> int:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=xdev)
+        dist.all_reduce(t)
+        return int(t.item())
 
-    def record(t):
-        full_ms.append(t.full_ms)
-        analysis_ms.append(t.analysis_ms)
-        emit_ms.append(t.emit_ms)
-        probe_ms.append(t.probe_ms)
-        ingest_ms.append(t.ingest_ms)
-        launches.append(max(1, t.full_launches))
-        api_ms.append(t.total_ms)
-        exec_ms.append(t.full_exec_ms)
+    def measure(total_frames: int, tag: str):
+        """Times `steps` encodes of this rank's block range of a `total_frames` stream; contract timing."""
+        total_blocks = (total_frames + BLOCK - 1) // BLOCK
+        b0 = rank * total_blocks // world
+        b1 = (rank + 1) * total_blocks // world
+        f0 = b0 * BLOCK
+        frames = min(b1 * BLOCK, total_frames) - f0
+        left, right = synth.synth_pcm(frames, 2, bit_depth, sample_rate, seed=2026, kind=args.kind, start=f0)
+        if interleaved:  # the WAV data-chunk layout: 2 (3) bytes per sample in HBM
+            inter = synth.interleave(left, right, bit_depth)
+            d_pcm = torch.from_numpy(inter.view(np.int16) if bit_depth == 16 else inter).cuda()
+            del inter
+        else:
+            d_left = torch.from_numpy(left).cuda()
+            d_right = torch.from_numpy(right).cuda()
+        torch.cuda.synchronize()
 
-    t0 = time.perf_counter()
-    last = run(args.steps, record)
-    sync()
-    elapsed = time.perf_counter() - t0
-    tm = enc.timing()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        def step():
+            if args.analysis_only:
+                enc.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
+                return None
+            if interleaved:
+                enc.encode_shard_pcm_device_begin(d_pcm.data_ptr(), layout, 2, frames, stream)
+                payload, table = enc.encode_shard_end()
+            else:
+                payload, table = enc.encode_shard_device_view(d_left.data_ptr(), d_right.data_ptr(), left, right, frames,
+                                                              stream)
+            if world > 1:
+                # the block table is already on the host: sum it there, exchange two integers per rank
+                mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device=xdev)
+                allv = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
+            return payload, table
+
+        for _ in range(args.warmup):
+            step()
+        sync()
+        rec = dict(full_ms=[], analysis_ms=[], emit_ms=[], probe_ms=[], ingest_ms=[], launches=[], api_ms=[], exec_ms=[])
+        last = None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+            t = enc.timing()
+            rec["full_ms"].append(t.full_ms)
+            rec["analysis_ms"].append(t.analysis_ms)
+            rec["emit_ms"].append(t.emit_ms)
+            rec["probe_ms"].append(t.probe_ms)
+            rec["ingest_ms"].append(t.ingest_ms)
+            rec["launches"].append(max(1, t.full_launches))
+            rec["api_ms"].append(t.total_ms)
+            rec["exec_ms"].append(t.full_exec_ms)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        tm = enc.timing()
+        return dict(tag=tag, total_frames=total_frames, total_blocks=total_blocks, b0=b0, b1=b1, frames=frames,
+                    elapsed=elapsed, last=last, rec=rec, timing=tm, left=left, right=right,
+                    value=total_frames * 2 * args.steps / elapsed / 1e6, ms_per_step=elapsed / args.steps * 1e3)
+
+    def lac_of(payload_bytes: bytes, table) -> bytes:
+        return lacx.assemble(sample_rate, bit_depth, STEREO_MODE, 2, [(payload_bytes, table)])
+
+    # ---- the headline measurement ----------------------------------------------------------------
+    workload = args.workload
+    if workload == "auto":
+        workload = "cfg2" if world == 1 else "cfg4"
+    std_format = bit_depth == 16 and sample_rate == 48000 and args.kind == "music"
+    if args.seconds:
+        total_frames, wl_name = args.seconds * sample_rate * world, f"{args.seconds} s per GPU (diagnostic)"
+    elif workload == "cfg2":
+        total_frames, wl_name = CFG2_SECONDS * sample_rate * world, "BASELINE configs[1]: 10 min per GPU"
+    else:
+        total_frames, wl_name = CFG4_SECONDS * sample_rate, "BASELINE configs[3]: one 2 h stream, contiguous block-range split over the ranks"
+    main = measure(total_frames, "main")
+
+    # ---- per-shard verification against the reference's golden digests (cfg4 eighths) ------------
+    shard_ok = None
+    if (workload == "cfg4" and not args.seconds and std_format and main["last"] is not None and world in (1, 2, 4, 8)):
+        payload, table = main["last"]
+        pay = payload.tobytes()
+        tab = np.array(table, dtype=np.uint32)
+        per = 8 // world
+        ok = True
+        off_blocks, off_bytes = 0, 0
+        for e in range(rank * per, (rank + 1) * per):
+            eb0, eb1 = e * main["total_blocks"] // 8, (e + 1) * main["total_blocks"] // 8
+            nbl = eb1 - eb0
+            t_e = tab[off_blocks:off_blocks + nbl]
+            nby = int(t_e[:, 1].sum(dtype=np.int64))
+            lac = lac_of(pay[off_bytes:off_bytes + nby], t_e)
+            d = digests.get(f"cfg4_2h_shard{e + 1}of8_st16_48k")
+            ok = ok and d is not None and len(lac) == d["lac_bytes"] and hashlib.sha256(lac).hexdigest() == d["lac_sha256"]
+            off_blocks += nbl
+            off_bytes += nby
+        ok = ok and off_blocks == tab.shape[0] and off_bytes == len(pay)
+        shard_ok = all_sum(1 if ok else 0)
+    ranks_seen = all_sum(1)
+
+    # ---- N > 1: the weak line (10 min per GPU) -----------------------------------------------------
+    weak = None
+    if world > 1 and workload == "cfg4" and not args.no_weak_line and not args.seconds:
+        w = measure(CFG2_SECONDS * sample_rate * world, "weak")
+        weak = {"value": round(w["value"], 3), "unit": "Msamples/s", "ms_per_step": round(w["ms_per_step"], 3),
+                "scaling": "weak", "workload": "10 min per GPU (BASELINE configs[1] material), rank r = r-th contiguous block range"}
+        del w
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
+    if shard_ok is not None and shard_ok != world:
+        raise SystemExit(f"bench.py: only {shard_ok}/{world} shards are byte-identical to the reference's -- refusing to report a number")
 
-    samples_all_ranks = total_frames * 2
-    value = samples_all_ranks * args.steps / elapsed / 1e6
-    ms_per_step = elapsed / args.steps * 1e3
+    rec, tm, frames = main["rec"], main["timing"], main["frames"]
+    mean = lambda k: float(np.mean(rec[k]))  # noqa: E731
 
     # ---- roofline of the dominant kernel: k_analyze<16,1024> (whole-block analysis) ----------
     # algorithmic bytes per launch = samples it analyses x bit_depth/8 (each PCM byte once, SURVEY 8d)
     # + the plan records it writes (296 B per analysed channel block).
     # The pipeline launches the kernel once per chunk: duration and bytes are per launch (averages).
     # Two live measurements of a launch: (a) hipEvents around it on its stream -- the contract's figure, used for
-    # `achieved`; with the pipeline's three chunks on three prioritised streams it includes the time a launch
-    # queues behind / shares the chip with the other chunks' kernels -- and (b) the span between the device-clock
-    # stamps of its first workgroup's start and last workgroup's end, which is what rocprofv3's kernel trace
-    # measures (profiles/*_kernel_stats_bench.csv).
-    n_launch = float(np.mean(launches))
-    kernel_s = float(np.mean(full_ms)) / 1e3 / n_launch
-    exec_s = float(np.mean(exec_ms)) / 1e3 / n_launch
-    algo_bytes = (frames * 2 * (BIT_DEPTH // 8) + tm.full_slots * 296) / n_launch
+    # `achieved`; with the pipeline's chunks on prioritised streams it includes the time a launch queues behind /
+    # shares the chip with the other chunks' kernels -- and (b) the span between the device-clock stamps of its first
+    # workgroup's start and last workgroup's end, which is what rocprofv3's kernel trace measures.
+    n_launch = mean("launches")
+    kernel_s = mean("full_ms") / 1e3 / n_launch
+    exec_s = mean("exec_ms") / 1e3 / n_launch
+    algo_bytes = (frames * 2 * (bit_depth // 8) + tm.full_slots * 296) / n_launch
     achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    default_run = (workload == "cfg2" and not args.seconds and world == 1 and not args.host_emit and std_format)
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench itself)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
-        if (args.seconds == SECONDS and world == 1 and not args.host_emit
-                and abs(n_launch - float(tj.get("launches_per_step", 2))) < 1e-9):
+        if default_run and abs(n_launch - float(tj.get("launches_per_step", 2))) < 1e-9:
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
+    valu = None
+    try:  # VALU-side roofline: wave-instruction counts from the committed SQ counter passes (profiles/valu.json)
+        with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
+            vj = json.load(f)
+        if default_run:
+            insts = float(vj["valu_wave_insts_per_step"]) / n_launch
+            valu = {
+                "wave_insts_per_launch": int(insts),
+                "lane_ops_per_sample": round(float(vj["valu_wave_insts_per_step"]) * 64 / (frames * 2), 1),
+                # issue slots used: one wave64 VALU instruction occupies a SIMD-32 for 2 cycles
+                "issue_frac": round(insts * 64 / (exec_s if exec_s > 0 else kernel_s) / VALU_LANE_OPS_PER_S, 4),
+                "valu_busy_frac_counters": vj.get("valu_busy_frac"),
+                "source": vj.get("source"),
+            }
+    except Exception:
+        valu = None
     roofline = {
         "bound": "hbm",
         "kernel": "k_analyze<16,1024>",
@@ -226,90 +335,143 @@ def main():
         "kernel_exec_ms": round(exec_s * 1e3, 4) if exec_s > 0 else None,
         "launches_per_step": n_launch,
         "algorithmic_bytes": int(algo_bytes),
+        "valu": valu,
         "note": "integer-VALU-bound search (~1e3 lane-ops/sample): HBM fraction is structurally small; "
                 "see DESIGN.md section 5",
     }
 
-    # ---- CPU baseline: the unmodified reference (oracle/_ref) on this box's host cores ----------
-    cpu = None
+    # ---- N = 1: CPU baseline (the unmodified reference, oracle/_ref) + byte comparison + end to end ----------
+    cpu = cpu_all = e2e = None
     identical = None  # set when the CPU leg encoded the whole stream: GPU bytes == CPU bytes
+    digest_ok = None
+    left, right = main["left"], main["right"]
+    gpu_lac = None
+    if world == 1 and main["last"] is not None:
+        gpu_lac = lac_of(main["last"][0].tobytes(), np.array(main["last"][1], dtype=np.uint32))
+        if default_run:
+            d = digests["cfg2_10min_st16_48k_auto"]
+            digest_ok = len(gpu_lac) == d["lac_bytes"] and hashlib.sha256(gpu_lac).hexdigest() == d["lac_sha256"]
+            if not digest_ok:
+                raise SystemExit("bench.py: the GPU .lac does not match the reference's golden digest -- refusing to report a number")
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
-        cores = emit_threads  # same CPU share as the GPU path's host emit
         try:
             import refshim
 
             have_ref = refshim.available()
         except Exception:
             have_ref = False
-        # bounded sample: the same stream, at most the whole 10-minute config (about 20 s of CPU work over the threads)
-        n_cpu = min(frames, 28_800_000)
-        t1 = time.perf_counter()
         if have_ref:
-            data = refshim.encode(left[:n_cpu], right[:n_cpu], SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, threads=cores)
-            kind = "reference"
+            cpu_encode, kind = refshim.encode, "reference"
         else:
             import oracleshim
 
-            data = oracleshim.encode(left[:n_cpu], right[:n_cpu], SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, threads=cores)
-            kind = "port"
-        dt = time.perf_counter() - t1
+            cpu_encode, kind = oracleshim.encode, "port"
+        # bounded sample: the same stream, at most the whole 10-minute config (about 20 s of CPU work over the threads)
+        n_cpu = min(frames, 28_800_000)
+
+        def cpu_leg(threads):
+            t1 = time.perf_counter()
+            data = cpu_encode(left[:n_cpu], right[:n_cpu], sample_rate, bit_depth, STEREO_MODE, threads=threads)
+            dt = time.perf_counter() - t1
+            return data, {
+                "value": round(n_cpu * 2 / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "host_cores": host_cores,
+                "kind": kind,
+                "sample": f"first {n_cpu} frames ({n_cpu / sample_rate:.0f} s) of the same stereo {bit_depth}-bit {sample_rate} Hz stream, "
+                          f"{dt:.2f} s wall, {len(data)} B .lac",
+            }
+
+        data, cpu = cpu_leg(emit_threads)  # the CPU share that belongs to one GPU on this box
         # outside every timed region: the last timed step's GPU output against the CPU encoder's, byte for byte
-        if last is not None and n_cpu == frames:
-            gpu_lac = lacx.assemble(SAMPLE_RATE, BIT_DEPTH, STEREO_MODE, 2, [(last[0].tobytes(), last[1].copy())])
+        if gpu_lac is not None and n_cpu == frames:
             identical = gpu_lac == data
             if not identical:
                 raise SystemExit("bench.py: the GPU .lac differs from the CPU encoder's -- refusing to report a number")
-        cpu = {
-            "value": round(n_cpu * 2 / dt / 1e6, 3),
-            "unit": "Msamples/s",
-            "cores": cores,
-            "kind": kind,
-            "sample": f"first {n_cpu} frames ({n_cpu / SAMPLE_RATE:.0f} s) of the same stereo {BIT_DEPTH}-bit {SAMPLE_RATE} Hz stream, "
-                      f"{dt:.2f} s wall, {len(data)} B .lac",
-        }
+        if host_cores > emit_threads:
+            data2, cpu_all = cpu_leg(host_cores)  # every host core of the box
+            if data2 != data:
+                raise SystemExit("bench.py: the CPU encoder's output depends on its thread count")
+            del data2
+        del data
+    if world == 1 and not args.no_end_to_end and not args.analysis_only and not args.host_emit:
+        # Host WAV image -> host .lac through lacx_encode_wav (RIFF walk, H2D of the raw data chunk, kernels, container):
+        # the PCIe-inclusive product path (ref src/main.cpp:658-697).  Never `value`.
+        import wavutil
+
+        wav = wavutil.make_wav(left, right, sample_rate, bit_depth)
+        enc.encode_wav(wav)  # warm-up (buffers)
+        times, h2d = [], []
+        out = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            out = enc.encode_wav(wav)
+            times.append(time.perf_counter() - t1)
+            h2d.append(enc.timing().h2d_ms)
+        best = min(times)
+        e2e = {"value": round(frames * 2 / best / 1e6, 3), "unit": "Msamples/s", "ms": round(best * 1e3, 3),
+               "h2d_ms": round(min(h2d), 3), "path": "host WAV image -> lacx_encode_wav -> host .lac (pageable host memory both sides)",
+               "byte_identical": (out == gpu_lac) if gpu_lac is not None else None}
+        if e2e["byte_identical"] is False:
+            raise SystemExit("bench.py: lacx_encode_wav output differs from the device-resident encode")
 
     out = {
-        "metric": "encode Msamples/s at 1/2/4/8 MI355X; byte-identical .lac vs CPU ref",
-        "value": round(value, 3),
+        "metric": METRIC,
+        "value": round(main["value"], 3),
         "unit": "Msamples/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
+        "ms_per_step": round(main["ms_per_step"], 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (workload == "cfg4" and not args.seconds) else "weak",
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.seconds} s per GPU synthetic stereo {BIT_DEPTH}-bit {SAMPLE_RATE // 1000} kHz ({args.kind}), auto MS/LR, LPC search, "
-                        "16384-frame blocks, zero-run + partitioning on (BASELINE configs[1])",
-            "frames_per_gpu": int(frames),
-            "blocks_per_gpu": int(b1 - b0),
+            "workload": f"{wl_name}: synthetic stereo {bit_depth}-bit {sample_rate // 1000} kHz ({args.kind}), auto MS/LR, LPC search, "
+                        "16384-frame blocks, zero-run + partitioning on",
+            "total_frames": int(main["total_frames"]),
+            "total_blocks": int(main["total_blocks"]),
+            "frames_rank0": int(frames),
+            "blocks_rank0": int(main["b1"] - main["b0"]),
             "host_emit_threads": emit_threads,
             "emit": "host" if args.host_emit else "device",
-            "encodes_in_flight": inflight,
-            "device_pcm_layout": (f"interleaved int{BIT_DEPTH} (WAV data chunk)" if interleaved else "planar int32"),
+            "device_pcm_layout": (f"interleaved int{bit_depth} (WAV data chunk)" if interleaved else "planar int32"),
             "timed_region": ("device analysis (PCM resident in HBM) + plan D2H + host emit + shard table" if args.host_emit
                              else "device analysis + device bit emit (PCM resident in HBM) + payload/table D2H into pinned host memory")
-                            + (" + RCCL all_gather of shard sizes" if world > 1 else ""),
+                            + (" + all_gather of shard sizes" if world > 1 else ""),
+            "exchange_backend": (None if world == 1 else ("gloo" if rehearse else "nccl (RCCL)")),
         },
+        "ranks_seen": ranks_seen,
+        "rehearsal_shared_gpu": bool(rehearse) if world > 1 else False,
+        "byte_identical_shards": (f"{shard_ok}/{world}" if shard_ok is not None else None),
+        "weak_10min_per_gpu": weak,
         "breakdown_ms": {
-            "device_analysis": round(float(np.mean(analysis_ms)), 3),
-            "k_ingest_levinson": round(float(np.mean(ingest_ms)), 3),
-            "k_probe_decide": round(float(np.mean(probe_ms)), 3),
-            "k_analyze_full": round(float(np.mean(full_ms)), 3),
-            ("host_emit_tail" if args.host_emit else "k_emit"): round(float(np.mean(emit_ms)), 3),
-            "api_call": round(float(np.mean(api_ms)), 3),
+            "device_analysis": round(mean("analysis_ms"), 3),
+            "k_ingest_levinson": round(mean("ingest_ms"), 3),
+            "k_probe_decide": round(mean("probe_ms"), 3),
+            "k_analyze_full": round(mean("full_ms"), 3),
+            ("host_emit_tail" if args.host_emit else "k_emit"): round(mean("emit_ms"), 3),
+            "api_call": round(mean("api_ms"), 3),
         },
-        "device_analysis_msamples_s": round(frames * 2 / (float(np.mean(analysis_ms)) / 1e3) / 1e6, 3),
+        "device_analysis_msamples_s": round(frames * 2 / (mean("analysis_ms") / 1e3) / 1e6, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_all,
+        "end_to_end": e2e,
         "byte_identical_to_cpu_baseline": identical,
+        "matches_golden_digest": digest_ok,
     }
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -91,7 +91,7 @@ typedef struct lacx_timing {
     uint64_t full_slots;    /* workgroups of the dominant kernel that did work */
     uint64_t probe_slots;
     uint32_t full_launches; /* launches of the dominant kernel in the call (one per pipeline chunk) */
-    uint32_t reserved;
+    uint32_t regrows;       /* device emit: times the pinned result buffer had to be regrown and the emit re-run */
     double full_exec_ms;    /* device emit pipeline: k_analyze<16,1024> execution spans (first workgroup start to last
                                workgroup end, device clock), summed over its launches -- full_ms minus queueing */
 } lacx_timing;
@@ -204,6 +204,11 @@ int lacx_debug_lpc(lacx_encoder* enc, const int32_t* pcm, uint32_t n, int64_t* a
 /* Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums of k_analyze<16,1024>; returns 0 in
  * production builds. out32[24] = number of waves accumulated. */
 int lacx_debug_stamps(unsigned long long* out32);
+
+/* Host-side worker threads the encoder's emit pool runs besides the calling thread (creates the pool; no device
+ * needed).  emit_threads = 1 must give 0: the reference's set_thread_count(1) means one thread in total
+ * (ref src/codec/lac/encoder.cpp:385-390). */
+int lacx_debug_emit_workers(lacx_encoder* enc);
 
 /* Number of visible HIP devices (0 when the runtime or a GPU is missing); does not initialise one. */
 int lacx_device_count(void);

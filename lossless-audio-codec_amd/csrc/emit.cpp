@@ -380,10 +380,10 @@ struct EmitPool::Impl {
 };
 
 EmitPool::EmitPool(unsigned threads) : impl_(new Impl) {
-    unsigned nt = threads ? threads : std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    impl_->workers.reserve(nt);
-    for (unsigned t = 0; t < nt; ++t) impl_->workers.emplace_back([this] { impl_->worker_main(); });
+    // `threads` extra workers, exactly: 0 means none (finish() runs the job on the calling thread, which is always
+    // the last worker).  "Auto" is resolved by the callers (pool_of in lacx_api.cpp, emit_blocks below).
+    impl_->workers.reserve(threads);
+    for (unsigned t = 0; t < threads; ++t) impl_->workers.emplace_back([this] { impl_->worker_main(); });
 }
 
 EmitPool::~EmitPool() {

@@ -18,6 +18,8 @@
 // The host emit (emit.cpp, LACX_FLAG_HOST_EMIT) consumes the same ChannelPlan records instead of k_offsets/k_emit.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "analyze_core.h"
 #include "emit_core.h"
 #include "kernels.h"
@@ -1110,6 +1112,7 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
 // ---------------------------------------------------------------------------------------------
 using GFull = Geo<16, 1024>;
 using GProbe = Geo<4, 64>;
+constexpr int kMaxDevices = 64;
 
 size_t analyze_smem_bytes_full() { return sizeof(Smem<GFull>); }
 
@@ -1126,17 +1129,39 @@ int debug_read_stamps(unsigned long long* out32) {
 }
 size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
 
+// The opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) applies to the device
+// that is current when it is set, and one process may drive several devices (one encoder per lacx_config.device):
+// the state is kept per device ordinal, under a mutex (first launches of two encoders may come from two host
+// threads), and only successes are remembered -- a transient failure is retried by the next call.
+static hipError_t ensure_kernel_attrs() {
+    static std::mutex mu;
+    static bool done[kMaxDevices] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GFull>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GFull>));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_levinson), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(LevMem));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emit<GFull>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitMem<GFull>));
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                        const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
                        hipEvent_t offsets_done, hipStream_t stream) {
-    static bool attr_done = false;
-    static hipError_t attr_err = hipSuccess;
-    if (!attr_done) {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emit<GFull>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EmitMem<GFull>));
-        attr_done = true;
-    }
+    const hipError_t attr_err = ensure_kernel_attrs();
     if (attr_err != hipSuccess) return attr_err;
     const uint32_t nb = prm.num_blocks;
     if (nb == 0) return hipSuccess;
@@ -1156,26 +1181,9 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
     return hipGetLastError();
 }
 
-static hipError_t set_smem_attr() {
-    static hipError_t cached = hipErrorUnknown;
-    static bool done = false;
-    if (!done) {
-        cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GFull>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GFull>));
-        if (cached == hipSuccess)
-            cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_levinson),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LevMem));
-        if (cached == hipSuccess)
-            cached = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
-        done = true;
-    }
-    return cached;
-}
-
 hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                            const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev) {
-    hipError_t e = set_smem_attr();
+    hipError_t e = ensure_kernel_attrs();
     if (e != hipSuccess) return e;
     const uint32_t nb = prm.num_blocks;
     if (nb == 0) return hipSuccess;

@@ -66,6 +66,11 @@ struct lacx_encoder {
         bool staged = false;
         hipStream_t st[4] = {};
         clk::time_point t0;
+        // inputs of the call, kept for the re-emit after a too-small result reservation
+        const int32_t* d_left = nullptr;
+        const int32_t* d_right = nullptr;
+        uint64_t frames = 0;
+        int layout = 0;
     } pend;
     hipEvent_t prologue = nullptr;  // per-call memsets done (the chunk streams wait for it)
     uint8_t* d_raw = nullptr;  // WAV data chunk as read from the file (lacx_encode_wav)
@@ -465,7 +470,24 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
     hipStream_t st[kStreams];
     for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
     if (user_stream) st[0] = user_stream;
+    // Work the caller queued on its stream (e.g. the kernel or copy that produces the PCM) must be ordered before
+    // every chunk, also those that run on the encoder's own streams: they wait for an event recorded on st[0].
+    {
+        const hipError_t pe = hipEventRecord(e->prologue, st[0]);
+        if (pe != hipSuccess) {
+            std::free(buf);
+            return hip_fail(e, pe, "event record");
+        }
+    }
     for (size_t c = 0; c < chunks.size(); ++c) {
+        if (c % kStreams != 0) {
+            const hipError_t we = hipStreamWaitEvent(st[c % kStreams], e->prologue, 0);
+            if (we != hipSuccess) {
+                (void)hipDeviceSynchronize();
+                std::free(buf);
+                return hip_fail(e, we, "stream wait");
+            }
+        }
         rc = enqueue_chunk(e, d_left, d_right, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, chunks[c],
                            (int)c, st[c % kStreams]);
         if (rc) {
@@ -530,12 +552,48 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
 // kernel straight into one pinned host buffer at global byte offsets (chunk c starts where chunk c-1 ends).
 // Results stay in encoder-owned pinned memory (e->h_payload, e->h_table).  Returns LACX_OK, an error, or -1 when the reservation of the
 // pinned buffer was too small (the caller then falls back to the host-emit pipeline, same bytes).
+// Kernel arguments of pipeline chunk c of a device-emit encode.
+struct ChunkCtx {
+    AnalyzeParams prm;
+    const int32_t* left;
+    const int32_t* right;
+    DeviceWorkspace w;
+};
+ChunkCtx chunk_ctx(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, int layout,
+                   int channels, const Chunk& ck, size_t c) {
+    ChunkCtx x;
+    const uint64_t frame_bytes = layout == 1 ? 2ull * channels : (layout == 2 ? 3ull * channels : 4ull);
+    const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
+    const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
+    x.prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
+    // chunk base pointers: planar int32 advances by frames, interleaved layouts by bytes
+    x.left = layout ? reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(d_left) + f0 * frame_bytes)
+                    : d_left + f0;
+    x.right = (!layout && d_right) ? d_right + f0 : nullptr;
+    x.w = ws_at(e->ws, ck.first);
+    x.w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
+    x.w.err_flag = e->ws.err_flag + c;
+    x.w.t_first = e->d_tspan + c;
+    x.w.t_last = e->d_tspan + kMaxChunks + c;
+    return x;
+}
+
+// Size of the pinned result reservation: 1.25 x the PCM at its source bit depth covers every realistic stream (the
+// exact size is only known after the analysis; a stream that needs more is re-emitted into a regrown buffer, see
+// reemit_into_regrown_buffer).  LACX_PINNED_CAP_BYTES overrides the estimate (tests force the regrow path with it).
+uint64_t pinned_reservation(const lacx_encoder* e, uint64_t frames, int channels, uint32_t nb) {
+    if (const char* env = std::getenv("LACX_PINNED_CAP_BYTES")) {
+        const unsigned long long v = std::strtoull(env, nullptr, 0);
+        if (v > 0) return (uint64_t)v;
+    }
+    return frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
+}
+
 // Part 1: enqueue everything (no host synchronisation).
 int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                         hipStream_t user_stream, int layout = 0, int layout_channels = 0) {
     if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
     const int channels = layout ? layout_channels : (d_right ? 2 : 1);
-    const uint64_t frame_bytes = layout == 1 ? 2ull * channels : (layout == 2 ? 3ull * channels : 4ull);
     const uint32_t nb = blocks_for(frames);
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
@@ -558,9 +616,8 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
             e->d_payload_cap = dev_cap;
         }
     }
-    // pinned result buffer: 1.25 x the PCM size at its source bit depth covers every realistic stream
-    const uint64_t host_cap = frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
-    if (host_cap > e->h_payload_cap) {
+    const uint64_t host_cap = pinned_reservation(e, frames, channels, nb);
+    if (host_cap > e->h_payload_cap || std::getenv("LACX_PINNED_CAP_BYTES")) {
         if (e->h_payload) (void)hipHostFree(e->h_payload);
         e->h_payload = nullptr;
         e->h_payload_cap = 0;
@@ -594,18 +651,10 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         const Chunk& ck = chunks[c];
         hipStream_t s = st[c % kStreams];
         if (c % kStreams != 0) HIP_TRY(e, hipStreamWaitEvent(s, e->prologue, 0), "stream wait");
-        const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
-        const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
-        const AnalyzeParams prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
-        // chunk base pointers: planar int32 advances by frames, interleaved layouts by bytes
-        const int32_t* cl = layout ? reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(d_left) + f0 * frame_bytes)
-                                   : d_left + f0;
-        const int32_t* cr = (!layout && d_right) ? d_right + f0 : nullptr;
-        DeviceWorkspace w = ws_at(e->ws, ck.first);
-        w.block_off = e->ws.block_off + ck.first + c;  // count + 1 entries per chunk
-        w.err_flag = e->ws.err_flag + c;
-        w.t_first = e->d_tspan + c;
-        w.t_last = e->d_tspan + kMaxChunks + c;
+        const ChunkCtx cx = chunk_ctx(e, d_left, d_right, frames, layout, channels, ck, c);
+        const AnalyzeParams& prm = cx.prm;
+        const int32_t *cl = cx.left, *cr = cx.right;
+        const DeviceWorkspace& w = cx.w;
         HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c]), "kernel launch");
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
         HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
@@ -630,6 +679,45 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     e->pend.staged = staged;
     for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
     e->pend.t0 = t0;
+    e->pend.d_left = d_left;
+    e->pend.d_right = d_right;
+    e->pend.frames = frames;
+    e->pend.layout = layout;
+    return LACX_OK;
+}
+
+// The pinned result buffer was reserved from an estimate and the stream needs more.  Every chunk's k_offsets has run
+// (offsets do not depend on the capacity) and the blocks that did not fit wrote nothing, so the exact total is known:
+// regrow the buffer and run only the emit kernels again, chunk by chunk, from the plans still in the workspace.
+int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size) {
+    const std::vector<Chunk>& chunks = e->pend.chunks;
+    HIP_TRY(e, hipDeviceSynchronize(), "synchronize");
+    const uint64_t total = e->h_totals[chunks.size() - 1];  // cumulative byte count after the last chunk
+    if (e->h_payload) (void)hipHostFree(e->h_payload);
+    e->h_payload = nullptr;
+    e->h_payload_cap = 0;
+    const uint64_t cap = total + 4096u;
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_payload, cap, 0), "hipHostMalloc(payload regrow)");
+    e->h_payload_cap = cap;
+    uint8_t* dst = nullptr;
+    HIP_TRY(e, hipHostGetDevicePointer((void**)&dst, e->h_payload, 0), "hipHostGetDevicePointer");
+    hipStream_t s = e->stream[0];
+    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, s), "memset");
+    const unsigned long long* prev_end = nullptr;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const ChunkCtx cx = chunk_ctx(e, e->pend.d_left, e->pend.d_right, e->pend.frames, e->pend.layout,
+                                      e->pend.channels, chunks[c], c);
+        HIP_TRY(e, launch_emit(cx.left, cx.right, cx.prm, cx.w, dst, cap, prev_end, nullptr, nullptr, s), "emit relaunch");
+        prev_end = cx.w.block_off + chunks[c].count;
+        HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], cx.w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
+    }
+    HIP_TRY(e, hipStreamSynchronize(s), "synchronize");
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        if (e->h_err[c] & 1u) return fail(e, LACX_E_RUNTIME, "device emit disagrees with the analysis plan (internal error)");
+        if ((e->h_err[c] & 2u) || e->h_totals[c] > cap)
+            return fail(e, LACX_E_RUNTIME, "payload exceeds the regrown result buffer (internal error)");
+    }
+    *payload_size = total;
     return LACX_OK;
 }
 
@@ -666,7 +754,7 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         }
         const uint64_t end = e->h_totals[c];  // cumulative
         if ((e->h_err[c] & 2u) || end > e->h_payload_cap) {
-            status = -1;  // reservation too small: let the caller use the host-emit pipeline
+            status = -1;  // reservation too small: re-emit into a regrown buffer below
             break;
         }
         if (staged) {
@@ -681,6 +769,18 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         off = end;
     }
     for (size_t c = 0; c < copies; ++c) (void)hipEventSynchronize(e->done[c]);
+    if (status == -1 && !staged) {
+        // no sample-range error can hide behind the overflow: wait for every chunk's block plans first
+        (void)hipDeviceSynchronize();
+        bool bad = false;
+        for (uint32_t b = 0; b < nb; ++b) bad = bad || e->h_bplans[b].invalid;
+        if (bad) {
+            status = LACX_E_INVALID;
+        } else {
+            status = reemit_into_regrown_buffer(e, &off);
+            e->timing.regrows += 1;
+        }
+    }
     e->timing.d2h_ms = ms_since(t0);
     if (status != LACX_OK) {
         (void)hipDeviceSynchronize();
@@ -1261,6 +1361,8 @@ int lacx_block_encode(lacx_encoder* e, const int32_t* pcm, uint32_t n, uint8_t**
 }
 
 int lacx_debug_stamps(unsigned long long* out32) { return debug_read_stamps(out32); }
+
+int lacx_debug_emit_workers(lacx_encoder* e) { return e ? (int)pool_of(e).threads() : -1; }
 
 int lacx_debug_lpc(lacx_encoder* e, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
                    uint8_t* used) {

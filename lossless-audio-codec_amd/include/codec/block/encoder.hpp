@@ -18,8 +18,24 @@ public:
     explicit Encoder(int order, bool debug_lpc = false, bool debug_zr = false)
         : order(order), debug_lpc(debug_lpc), debug_zr(debug_zr) {}
     ~Encoder() { reset(); }
-    Encoder(const Encoder&) = delete;
-    Encoder& operator=(const Encoder&) = delete;
+    // Copyable like the reference's class: a copy takes the settings and creates its own device handle lazily.
+    Encoder(const Encoder& o)
+        : order(o.order), debug_lpc(o.debug_lpc), debug_zr(o.debug_zr), zero_run_enabled(o.zero_run_enabled),
+          partitioning_enabled(o.partitioning_enabled), debug_partitions(o.debug_partitions),
+          block_index(o.block_index), enc(nullptr) {}
+    Encoder& operator=(const Encoder& o) {
+        if (this != &o) {
+            reset();
+            order = o.order;
+            debug_lpc = o.debug_lpc;
+            debug_zr = o.debug_zr;
+            zero_run_enabled = o.zero_run_enabled;
+            partitioning_enabled = o.partitioning_enabled;
+            debug_partitions = o.debug_partitions;
+            block_index = o.block_index;
+        }
+        return *this;
+    }
 
     // input: int32_t PCM block; output: compressed block as bytes (ref block/encoder.cpp:313-838)
     std::vector<uint8_t> encode(const std::vector<int32_t>& pcm) {

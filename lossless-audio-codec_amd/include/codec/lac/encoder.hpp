@@ -23,8 +23,30 @@ public:
         : order(order), stereo_mode(stereo_mode), sample_rate(sample_rate), bit_depth(bit_depth), debug_lpc(debug_lpc),
           debug_stereo_est(debug_stereo_est), debug_zr(debug_zr) {}
     ~Encoder() { reset(); }
-    Encoder(const Encoder&) = delete;
-    Encoder& operator=(const Encoder&) = delete;
+    // Copyable like the reference's class (a plain aggregate of settings there): a copy takes the settings and
+    // creates its own device handle lazily, on its first encode.
+    Encoder(const Encoder& o)
+        : order(o.order), stereo_mode(o.stereo_mode), sample_rate(o.sample_rate), bit_depth(o.bit_depth),
+          debug_lpc(o.debug_lpc), debug_stereo_est(o.debug_stereo_est), debug_zr(o.debug_zr),
+          zero_run_enabled(o.zero_run_enabled), partitioning_enabled(o.partitioning_enabled),
+          debug_partitions(o.debug_partitions), thread_count(o.thread_count), enc(nullptr) {}
+    Encoder& operator=(const Encoder& o) {
+        if (this != &o) {
+            reset();
+            order = o.order;
+            stereo_mode = o.stereo_mode;
+            sample_rate = o.sample_rate;
+            bit_depth = o.bit_depth;
+            debug_lpc = o.debug_lpc;
+            debug_stereo_est = o.debug_stereo_est;
+            debug_zr = o.debug_zr;
+            zero_run_enabled = o.zero_run_enabled;
+            partitioning_enabled = o.partitioning_enabled;
+            debug_partitions = o.debug_partitions;
+            thread_count = o.thread_count;
+        }
+        return *this;
+    }
 
     std::vector<uint8_t> encode(const std::vector<int32_t>& left, const std::vector<int32_t>& right,
                                 ThreadCollector* collector = nullptr) {

@@ -76,7 +76,7 @@ class Timing(C.Structure):
         ("full_slots", C.c_uint64),
         ("probe_slots", C.c_uint64),
         ("full_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("regrows", C.c_uint32),
         ("full_exec_ms", C.c_double),
     ]
 
@@ -86,7 +86,7 @@ EXPORTS = (
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
-    "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end",
+    "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers",
 )
 
 

@@ -58,6 +58,13 @@ DIGESTS = [
     ("cfg4_2h_shard8of8_st16_48k", 345_600_000 - 18457 * 16384, 2, 16, 48000, 2, "music", "wide", 2026, False, True,
      18457 * 16384),
 ]
+# The other seven eighths of the same 2 h stream (block ranges [r*B/8, (r+1)*B/8), B = 21 094): bench.py --gpus 2/4/8
+# has every rank check each eighth of its shard against these (the N = 2 and N = 4 boundaries are N = 8 boundaries).
+CFG4_FRAMES, CFG4_BLOCKS = 345_600_000, 21094
+for _r in range(7):
+    _b0, _b1 = _r * CFG4_BLOCKS // 8, (_r + 1) * CFG4_BLOCKS // 8
+    DIGESTS.append((f"cfg4_2h_shard{_r + 1}of8_st16_48k", (_b1 - _b0) * 16384, 2, 16, 48000, 2, "music", "wide", 2026,
+                    False, _r in (0, 3), _b0 * 16384))
 
 
 def main():
@@ -65,7 +72,7 @@ def main():
         raise SystemExit("oracle/_ref/liblac_ref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(os.path.join(HERE, "small"), exist_ok=True)
     index = []
-    for name, frames, ch, bd, sr, sm, kind, st, seed in SMALL:
+    for name, frames, ch, bd, sr, sm, kind, st, seed in (SMALL if not (len(sys.argv) > 2 and sys.argv[1] == "--only") else []):
         left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st)
         data = refshim.encode(left, right, sr, bd, sm)
         with open(os.path.join(HERE, "small", name + ".lac"), "wb") as f:
@@ -74,11 +81,18 @@ def main():
                           gen=dict(frames=frames, channels=ch, bit_depth=bd, sample_rate=sr, seed=seed, kind=kind,
                                    stereo=st)))
         print(name, len(data))
-    with open(os.path.join(HERE, "small", "index.json"), "w") as f:
-        json.dump(index, f, indent=1)
+    if index:
+        with open(os.path.join(HERE, "small", "index.json"), "w") as f:
+            json.dump(index, f, indent=1)
     out = []
+    only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--only" else None
+    if only:  # re-mint the entries whose name starts with the prefix, keep the others as they are
+        with open(os.path.join(HERE, "digests.json")) as f:
+            out = [d for d in json.load(f) if not d["name"].startswith(only)]
     for ent in DIGESTS:
         name, frames, ch, bd, sr, sm, kind, st, seed, cpu_test, gpu_test = ent[:11]
+        if only and not name.startswith(only):
+            continue
         start = ent[11] if len(ent) > 11 else 0
         left, right = synth.synth_pcm(frames, ch, bd, sr, seed=seed, kind=kind, stereo=st, start=start)
         data = refshim.encode(left, right, sr, bd, sm)
@@ -87,6 +101,8 @@ def main():
                         gen=dict(frames=frames, channels=ch, bit_depth=bd, sample_rate=sr, seed=seed, kind=kind,
                                  stereo=st, start=start)))
         print(name, len(data), out[-1]["lac_sha256"][:16])
+    order = {ent[0]: i for i, ent in enumerate(DIGESTS)}
+    out.sort(key=lambda d: order.get(d["name"], len(order)))
     with open(os.path.join(HERE, "digests.json"), "w") as f:
         json.dump(out, f, indent=1)
 

@@ -368,3 +368,89 @@ def test_cli_encode_command(gpu, oracle, tmp_path):
     bad = subprocess.run([cli, "encode", str(tmp_path / "missing.wav"), str(tmp_path / "x.lac")], capture_output=True, text=True)
     assert bad.returncode == 1 and "Failed to read WAV" in bad.stderr
     assert subprocess.run([cli, "encode", str(wav), str(wav)], capture_output=True).returncode == 1
+
+
+def test_two_encoders_on_two_host_threads(gpu, oracle):
+    """Two encoders whose first launches come from two host threads at once (the per-device kernel attribute state is
+    shared and mutex-protected): same bytes as the oracle from both."""
+    import threading
+
+    cases = []
+    for seed in (61, 62):
+        left, right = gpu.synth.synth_pcm(16384 * 4 + 100 * seed, 2, 16, 48000, seed=seed, kind="mixed")
+        cases.append((left, right, oracle.encode(left, right, 48000, 16, 2, threads=8)))
+    got = [None, None]
+
+    def run(i):
+        try:
+            enc = gpu.lacx.Encoder(12, 2, 48000, 16, device=0)
+            for _ in range(3):
+                got[i] = enc.encode(cases[i][0], cases[i][1])
+        except Exception as ex:  # noqa: BLE001
+            got[i] = ex
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(2):
+        assert got[i] == cases[i][2], got[i] if isinstance(got[i], Exception) else "bytes differ"
+
+
+def test_two_devices_in_one_process(gpu, oracle):
+    """One encoder per GPU in one process (lacx_config.device): the > 64 KiB dynamic-LDS opt-in is per device."""
+    if gpu.lacx.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    left, right = gpu.synth.synth_pcm(16384 * 3 + 77, 2, 16, 48000, seed=63, kind="mixed")
+    want = oracle.encode(left, right, 48000, 16, 2, threads=8)
+    for dev in (1, 0, 1):
+        assert gpu.lacx.Encoder(12, 2, 48000, 16, device=dev).encode(left, right) == want
+
+
+def test_pinned_reservation_regrows(gpu, oracle, monkeypatch):
+    """A result larger than the pinned reservation (forced tiny here) is re-emitted into a regrown buffer, not an
+    error: every device-emit entry point still returns the reference's bytes."""
+    import wavutil as W
+
+    left, right = gpu.synth.synth_pcm(16384 * 6 + 1234, 2, 16, 48000, seed=64, kind="noise", stereo="independent")
+    want = oracle.encode(left, right, 48000, 16, 2, threads=8)
+    monkeypatch.setenv("LACX_PINNED_CAP_BYTES", "100000")  # the stream needs about 0.4 MB
+    enc = gpu.lacx.Encoder(12, 2, 48000, 16, device=0)
+    assert enc.encode(left, right) == want
+    assert enc.timing().regrows == 1
+    assert enc.encode_wav(W.make_wav(left, right, 48000, 16)) == want
+    assert enc.timing().regrows == 1
+    payload, table = enc.encode_shard(left, right)
+    assert gpu.lacx.assemble(48000, 16, 2, 2, [(payload, table)]) == want
+    monkeypatch.delenv("LACX_PINNED_CAP_BYTES")
+    assert enc.encode(left, right) == want
+    assert enc.timing().regrows == 0
+
+
+def test_host_emit_waits_for_the_callers_stream(gpu, oracle):
+    """Host-emit pipeline with PCM produced asynchronously on the caller's stream: chunks that run on the encoder's own
+    streams must be ordered behind it (>= 384 blocks, so that the pipeline has more than one chunk)."""
+    import torch
+
+    frames = 16384 * 400 + 5
+    left, right = gpu.synth.synth_pcm(frames, 2, 16, 48000, seed=65, kind="music")
+    want = oracle.encode(left, right, 48000, 16, 2, threads=8)
+    hl, hr = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    side = torch.cuda.Stream()
+    enc = gpu.lacx.Encoder(12, 2, 48000, 16, device=0)
+    enc.set_host_emit(True)
+    for _ in range(2):
+        dl = torch.zeros(frames, dtype=torch.int32, device="cuda")
+        dr = torch.zeros(frames, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            # a long fill first, so that the copies are still pending when the encode is enqueued
+            junk = torch.empty(1 << 28, dtype=torch.int32, device="cuda")
+            for _k in range(4):
+                junk.fill_(_k)
+            dl.copy_(hl, non_blocking=True)
+            dr.copy_(hr, non_blocking=True)
+            got = enc.encode_device(dl.data_ptr(), dr.data_ptr(), left, right, frames, side.cuda_stream)
+        assert got == want
+        del junk

@@ -133,3 +133,17 @@ def test_cpp_mirror_classes_compile_and_validate_arguments(pkg):
 
     rc = subprocess.call([_build_mirror_test()])
     assert rc in (0, 77)  # 77 = no HIP device: only the argument / loud-failure checks ran
+
+
+def test_thread_count_one_means_no_extra_emit_workers(pkg):
+    """set_thread_count(1) is one thread in total (ref src/codec/lac/encoder.cpp:385-390): the emit pool then runs on the
+    calling thread alone; N threads = N - 1 workers besides the caller."""
+    import ctypes as C
+
+    L = pkg.lacx.lib()
+    L.lacx_debug_emit_workers.argtypes = [C.c_void_p]
+    for n, want in ((1, 0), (2, 1), (5, 4)):
+        enc = pkg.lacx.Encoder(12, 2, 48000, 16)
+        enc.set_thread_count(n)
+        assert L.lacx_debug_emit_workers(enc._handle()) == want
+        enc.close()
