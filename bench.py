@@ -453,6 +453,7 @@ def worker(args) -> int:
             ("host_emit_tail" if args.host_emit else "k_emit"): round(mean("emit_ms"), 3),
             "api_call": round(mean("api_ms"), 3),
         },
+        "fused_emit": {"streamed_out_beside_the_analysis": int(tm.emit_direct), "channel_blocks": int(tm.full_slots)},
         "device_analysis_msamples_s": round(frames * 2 / (mean("analysis_ms") / 1e3) / 1e6, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,

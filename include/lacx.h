@@ -94,6 +94,8 @@ typedef struct lacx_timing {
     uint32_t regrows;       /* device emit: times the pinned result buffer had to be regrown and the emit re-run */
     double full_exec_ms;    /* device emit pipeline: k_analyze<16,1024> execution spans (first workgroup start to last
                                workgroup end, device clock), summed over its launches -- full_ms minus queueing */
+    uint32_t emit_direct;   /* fused emit: channel blocks the streaming packer moved to the payload beside the analysis */
+    uint32_t emit_parked;   /* reserved */
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);

@@ -200,12 +200,23 @@ struct PartMem {
     unsigned long long pbits[G::MAXP + 1];
 };
 
+// Output side of the device emit (emit_core.h): the bit tile and the Rice parameter in force per sample.  Aliases the
+// staged samples / the partition scratch in the analysis kernel's image (whole-block geometry only).
+constexpr int kEmitTileWords = 12288;  // 48 KiB output tile (393216 bits)
+template <class G>
+struct EmitOut {
+    uint32_t obits[kEmitTileWords];  // output tile, big-endian bit order inside each word
+    uint8_t kin[G::MAXN];            // Rice parameter in force per sample (transposed)
+};
+struct NoEmitOut {};
+
 template <class G>
 struct Smem {
     uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate (transposed); bits 30/31 = micro flags; +4: peek_u looks up to 3 samples past the slot
     union XP {
         int32_t x[G::MAXN];  // staged samples (transposed), zero beyond n
         PartMem<G> part;
+        typename std::conditional<G::T == 1024, EmitOut<G>, NoEmitOut>::type o;  // fused emit (after the plan is final)
     } xp;
     uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
@@ -224,6 +235,16 @@ struct Smem {
     int32_t best_cand;
     uint32_t cur_k0;
     LpcSet lpc;
+    // the finished plan (thread 0 writes it here, then it is copied out cooperatively) and, for the emit fused into the
+    // whole-block analysis kernel, the fields the emit phases of emit_core.h read (same names as in EmitMem)
+    ChannelPlan plan;
+    int32_t tabNX[G::T + 1];  // first non-zero index per chunk -> exclusive suffix min
+    int32_t wx[16];
+    uint8_t part_mode_k[kMaxParts];
+    uint32_t ptype, order, p, parts, cand, header_bits, payload_bytes;
+    uint32_t err;
+    unsigned long long lb_off;  // byte offset of this channel block in the shard payload (decoupled look-back)
+    uint32_t lb_ok;
 };
 
 template <class G>

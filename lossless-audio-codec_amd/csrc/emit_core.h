@@ -15,17 +15,12 @@
 
 namespace lacx {
 
-constexpr int kEmitTileWords = 12288;  // 48 KiB output tile (393216 bits)
-
 template <class G>
 struct EmitMem {
     uint32_t u[G::MAXN + 4];  // zigzag residual (transposed); bits 30/31 = micro flags during the stateful walk; +4: lookahead pad
     union XP {
         int32_t x[G::MAXN];  // staged samples until the residual is formed
-        struct Out {
-            uint32_t obits[kEmitTileWords];  // output tile, big-endian bit order inside each word
-            uint8_t kin[G::MAXN];            // Rice parameter in force per sample (transposed)
-        } o;
+        EmitOut<G> o;        // output tile + Rice parameter per sample (analyze_core.h)
     } xp;
     uint64_t tabP[G::T + 1];  // chunk sums -> exclusive prefix; later: bit counts -> bit offsets
     int32_t tabNZ[G::T + 1];  // last non-zero index -> exclusive prefix max
@@ -41,8 +36,8 @@ struct EmitMem {
 };
 
 // plan -> shared memory (thread 0) ---------------------------------------------------------------
-template <class G>
-LACX_HD void emit_load_plan(EmitMem<G>& sh, const ChannelPlan& pl, int tid = 0, int nthreads = 1) {
+template <class M>
+LACX_HD void emit_load_plan(M& sh, const ChannelPlan& pl, int tid = 0, int nthreads = 1) {
     // cooperative: every element is written by exactly one of the `nthreads` callers (a single caller does it all)
     const uint32_t parts = pl.partition_order ? (1u << pl.partition_order) : 1u;
     const uint32_t order = pl.order;
@@ -69,8 +64,8 @@ LACX_HD void emit_load_plan(EmitMem<G>& sh, const ChannelPlan& pl, int tid = 0, 
 }
 
 // first non-zero index of the chunk (n if none); input of the suffix-min scan
-template <class G>
-LACX_HD void emit_first_nonzero(const Thread<G>& th, EmitMem<G>& sh) {
+template <class G, class M>
+LACX_HD void emit_first_nonzero(const Thread<G>& th, M& sh) {
     int32_t first = (int32_t)th.n;
     for (int i = th.cnt - 1; i >= 0; --i) {
         if ((sh.u[i * G::T + th.tid] & 0x3FFFFFFFu) != 0) first = th.a + i;
@@ -181,8 +176,8 @@ LACX_HD uint64_t put_rice(const BitTile* tile, uint64_t pos, uint32_t u, uint32_
 // One walk over the thread's chunk.  PASS 1 (tile == nullptr): computes kin per sample (stored in
 // sh.xp.o.kin) and returns the thread's token bits.  PASS 2: writes the tokens starting at bit `pos`.
 // The walk mirrors phase_b (stateful, p == 0) / partition_pass (stateless, p > 0).
-template <class G, bool NARROW, bool PASS1, class Or, class St>
-LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile_in, uint64_t pos, Or&& or_word,
+template <class G, bool NARROW, bool PASS1, class M, class Or, class St>
+LACX_HD uint64_t emit_walk_t(const Thread<G>& th, M& sh, const BitTile* tile_in, uint64_t pos, Or&& or_word,
                              St&& st_word) {
     if (th.cnt <= 0) return 0;
     const BitTile* tile = PASS1 ? nullptr : tile_in;
@@ -330,16 +325,16 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, EmitMem<G>& sh, const BitTile*
 }
 
 // PASS 1 when tile == nullptr, PASS 2 otherwise (the second pass does not depend on the prefix-sum width)
-template <class G, bool NARROW, class Or, class St>
-LACX_HD uint64_t emit_walk(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile, uint64_t pos, Or&& or_word,
+template <class G, bool NARROW, class M, class Or, class St>
+LACX_HD uint64_t emit_walk(const Thread<G>& th, M& sh, const BitTile* tile, uint64_t pos, Or&& or_word,
                            St&& st_word) {
     if (tile == nullptr) return emit_walk_t<G, NARROW, true>(th, sh, nullptr, pos, or_word, st_word);
     return emit_walk_t<G, true, false>(th, sh, tile, pos, or_word, st_word);
 }
 
 // Header fields (ref block/encoder.cpp:773-795), spread over the first threads.
-template <class G, class Or>
-LACX_HD void emit_header(const Thread<G>& th, EmitMem<G>& sh, const BitTile* tile, Or&& or_word) {
+template <class G, class M, class Or>
+LACX_HD void emit_header(const Thread<G>& th, M& sh, const BitTile* tile, Or&& or_word) {
     const uint32_t t = (uint32_t)th.tid;
     const uint32_t lpc_bits = sh.ptype == 2 ? 16u * sh.order : 0u;
     if (t == 0) {

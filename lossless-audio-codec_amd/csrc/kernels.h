@@ -23,19 +23,48 @@ struct DeviceWorkspace {
     // ended: its execution span without the time it queued behind other streams (null = not recorded)
     unsigned long long* t_first = nullptr;
     unsigned long long* t_last = nullptr;
+    // Emit fused into the whole-block analysis kernel (shard-wide arrays, indexed by stream index = block * channels +
+    // channel; NOT advanced per pipeline chunk): one fixed-stride staging slot per channel block and a "bitstream is in
+    // its slot" flag.
+    uint8_t* slots = nullptr;
+    unsigned long long slot_stride = 0;
+    uint32_t* emitted = nullptr;              // 2: the analysis kernel put the bitstream into the slot
+    uint32_t* packed = nullptr;               // 1: the streaming packer moved it to the payload
+    unsigned long long* size_rec = nullptr;   // hand-off words of the fused emit (see kernels.hip)
+    unsigned long long* ready_rec = nullptr;
+};
+
+// Where the whole-block analysis kernel writes a channel block's bitstream as soon as its plan is final (slots == null:
+// no fused emit; the bitstream then comes from k_offsets + k_emit alone).
+struct FuseArgs {
+    uint8_t* slots = nullptr;
+    unsigned long long slot_stride = 0;
+    uint32_t* emitted = nullptr;            // per stream index: 2 = bitstream is in its slot, 0 = not emitted
+    uint32_t* err_flag = nullptr;
+    unsigned long long* size_rec = nullptr;   // per stream index: 1 << 62 | ms << 61 | bytes, once the plan is final
+    unsigned long long* ready_rec = nullptr;  // per stream index: 1 slot published, 2 nothing will come
+    uint32_t fuse_items = 0;                  // stream indices below this one take part (a small final block does not)
 };
 
 // Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).
 // ev: optional 5 events recorded at: start, after ingest+levinson, after probes+decide, after the
-// whole-block analysis kernel, end.
+// whole-block analysis kernel, end.  wait_before_full: optional event the whole-block analysis kernel waits for.
 hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev);
+                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
+                           const FuseArgs* fuse = nullptr, hipEvent_t wait_before_full = nullptr);
 
-// Device-side emit of the analysed blocks of one chunk into d_payload (k_offsets + k_emit).
+// Device-side emit of the analysed blocks of one chunk into the shard payload: k_offsets (block byte offsets), k_pack
+// (channel blocks the fused emit left in their staging slots: ws.emitted set) and k_emit (all others).
+// skip_emitted = false: k_emit emits everything (re-emit into a regrown buffer).
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                        const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
-                       hipEvent_t offsets_done, hipStream_t stream);
+                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted = true);
+
+// The streaming packer of the fused emit: runs beside the analysis kernels on its own stream and moves the staging
+// slots of stream indices [0, fuse_items) to their place in `out` as they are published.
+hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
+                             unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream);
 
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.

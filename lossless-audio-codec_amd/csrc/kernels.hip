@@ -18,6 +18,7 @@
 // The host emit (emit.cpp, LACX_FLAG_HOST_EMIT) consumes the same ChannelPlan records instead of k_offsets/k_emit.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "analyze_core.h"
@@ -38,19 +39,6 @@ __device__ unsigned long long g_stamp_acc[32];
 #else
 #define STAMP(k) do { } while (0)
 #endif
-// -DLACX_STAMPS=2: the same for k_emit (its stamps land in the same accumulator; k_analyze's still run but the
-// reader is expected to launch the emit only after a reset)
-#if defined(LACX_STAMPS) && LACX_STAMPS == 2
-#define ESTAMP(k)                                                       \
-    do {                                                                \
-        const unsigned long long _now = __builtin_amdgcn_s_memtime();   \
-        estamp_acc[k] += _now - estamp_prev;                            \
-        estamp_prev = _now;                                             \
-    } while (0)
-#else
-#define ESTAMP(k) do { } while (0)
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
@@ -568,6 +556,230 @@ __global__ __launch_bounds__(kLevThreads) void k_levinson(AnalyzeParams prm, con
     out->pad = 0;
 }
 
+// suffix-min scan of tabNX (first non-zero index per chunk) -> exclusive: min over later chunks
+template <class G, class M>
+__device__ __forceinline__ int32_t scan_nx_part1(M& sh, int tid, int32_t* wtot) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t v = sh.tabNX[tid];
+    int32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc = o < inc ? o : inc;
+    }
+    if (lane == 0) wtot[wave] = inc;
+    return inc;
+}
+
+template <class G, class M>
+__device__ __forceinline__ void scan_nx_part2(M& sh, int tid, int32_t inc, const int32_t* wtot, int32_t n) {
+    constexpr int NW = G::T / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t later = n;
+    for (int w = wave + 1; w < NW; ++w) later = wtot[w] < later ? wtot[w] : later;
+    int32_t next = __shfl_down(inc, 1, 64);
+    if (lane == 63) next = n;
+    sh.tabNX[tid] = next < later ? next : later;
+}
+
+
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for the wave's global stores
+// (s_waitcnt vmcnt(0)); between the output tiles of the emit that would park every wave until its stores have crossed
+// PCIe into the pinned host buffer, although nothing on the device reads them.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Emit of one channel block from the residual in sh.u (plain zigzag values, block scans of tabP / tabNZ / tabNX done,
+// plan fields loaded): walk 1 (Rice parameter per sample + token bits), bit offsets, walk 2 into 48 KiB LDS tiles,
+// copy-out.  `resolve` is called once by all threads (it may contain barriers) before the first byte leaves the
+// workgroup and yields the address the channel block's bitstream goes to; false from it abandons the emit.  Returns
+// true when the whole bitstream was written.  Shared by k_emit and the emit fused into the analysis kernel.
+template <class G, class M, class Resolve>
+__device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint8_t* __restrict__ out,
+                                          uint32_t* __restrict__ err_flag, Resolve&& resolve, const int tid,
+                                          const bool ablate_stores = false, const uint32_t slot_bytes = 0) {
+    (void)out;
+    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
+    if (adaptive0) {
+        if (narrow) {
+            phase_a<G, true>(th, sh);
+        } else {
+            phase_a<G, false>(th, sh);
+        }
+        __syncthreads();
+    }
+    auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
+    auto stw = [](uint32_t* w, uint32_t v) { *w = v; };
+    // walk 1: Rice parameter per sample + token bits of the chunk
+    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw, stw)
+                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw, stw);
+    __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
+    sh.tabP[tid] = mybits;
+    {
+        // sum scan of the bit counts (tabP only)
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long inc = wave_scan_add_u64(mybits);
+        if (lane == 63) sh.wtotP[wave] = inc;
+        __syncthreads();
+        unsigned long long base = 0;
+        for (int w = 0; w < wave; ++w) base += sh.wtotP[w];
+        sh.tabP[tid] = base + inc - mybits;
+        if (tid == G::T - 1) sh.tabP[G::T] = base + inc;
+        __syncthreads();
+    }
+    const unsigned long long total_bits = sh.tabP[G::T] + sh.header_bits;
+    const unsigned long long nbytes = (total_bits + 7u) >> 3;
+    if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
+    if (nbytes != sh.payload_bytes || sh.err) return false;  // uniform: never write outside the planned byte range
+    const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
+
+    // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
+    uint8_t* base = nullptr;
+    for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
+        if (bit0 != 0) lds_barrier();  // every thread has copied its part of the previous tile out of LDS
+        for (int i = tid; i < kEmitTileWords; i += G::T) sh.xp.o.obits[i] = 0;
+        lds_barrier();
+        BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
+        if (bit0 == 0) emit_header(th, sh, &tile, orw);
+        const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
+        if (mypos < tile_end && mypos + mybits > bit0) {
+            if (narrow) {
+                emit_walk<G, true>(th, sh, &tile, mypos, orw, stw);
+            } else {
+                emit_walk<G, false>(th, sh, &tile, mypos, orw, stw);
+            }
+        }
+        lds_barrier();
+        if (bit0 == 0 && !resolve(&base)) return false;  // uniform
+        const unsigned long long byte0 = bit0 >> 3;
+        const unsigned long long left = nbytes - byte0;
+        const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
+        // Copy-out in 16-byte stores on 16-byte boundaries of the destination (which may be pinned host
+        // memory behind PCIe: whole, aligned segments matter there); the unaligned head and tail go bytewise.
+        uint8_t* dst = base + byte0;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const uint32_t head = mis ? (16u - mis < count ? 16u - mis : count) : 0u;
+        const uint32_t nvec = (count - head) >> 4;
+        const uint32_t* tw = sh.xp.o.obits;
+        auto tile_byte = [&](uint32_t i) { return (uint8_t)(tw[i >> 2] >> (24u - 8u * (i & 3u))); };
+        if (ablate_stores) continue;  // timing ablation only (LACX_DEBUG_SKIP bit 11)
+        if (slot_bytes) {
+            // Staging slot (16-byte aligned, padded): whole 16-byte vectors only, stored write-through (sc1) so that
+            // the hand-off to the streaming packer needs no release fence (cdna_hip_programming.md, Guideline 16, R1).
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)slot_bytes, 0x00020000);
+            const uint32_t nv = (count + 15u) >> 4;
+            for (uint32_t v = tid; v < nv; v += G::T) {
+                u32x4 o;
+                o.x = __builtin_bswap32(tw[4u * v]);
+                o.y = __builtin_bswap32(tw[4u * v + 1u]);
+                o.z = __builtin_bswap32(tw[4u * v + 2u]);
+                o.w = __builtin_bswap32(tw[4u * v + 3u]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (int)((uint32_t)byte0 + 16u * v), 0, 16 /* sc1 */);
+            }
+            continue;
+        }
+        if ((uint32_t)tid < head) dst[tid] = tile_byte((uint32_t)tid);
+        {
+            const uint32_t r = head & 3u, j0 = head >> 2;
+            uint4* vdst = reinterpret_cast<uint4*>(dst + head);
+            for (uint32_t v = tid; v < nvec; v += G::T) {
+                const uint32_t j = j0 + 4u * v;
+                uint32_t w[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const uint32_t jj = j + q < (uint32_t)kEmitTileWords ? j + q : (uint32_t)kEmitTileWords - 1u;
+                    w[q] = __builtin_bswap32(tw[jj]);  // bytes of the stream in memory order
+                }
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbyte(w[1], w[0], r);
+                o.y = __builtin_amdgcn_alignbyte(w[2], w[1], r);
+                o.z = __builtin_amdgcn_alignbyte(w[3], w[2], r);
+                o.w = __builtin_amdgcn_alignbyte(w[4], w[3], r);
+                vdst[v] = o;
+            }
+        }
+        {
+            const uint32_t t0 = head + (nvec << 4);
+            if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
+        }
+        // no barrier and no wait for the stores here: the workgroup may retire while they are still on their way
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused emit + streaming packer.
+// The whole-block analysis kernel emits a channel block's bitstream right after its plan is final, while the winner's
+// residual (plain, in sh.u) and its block scans are still in LDS -- no re-staging of the PCM, no second residual pass.
+// Where the bytes belong in the shard payload depends on the sizes of all earlier channel blocks, so the workgroup
+// writes them to the channel block's staging slot in device memory (fixed stride, 16-byte aligned) and retires: no
+// analysis workgroup ever waits for another one.  A small companion kernel, k_stream_out, runs beside the analysis
+// on its own stream: it walks the stream indices in order, waits for each slot to be published, keeps the running
+// byte offset and copies slot after slot to its place in the payload (pinned host memory: the bytes cross PCIe while
+// later blocks are still being analysed, nothing is left to copy when the analysis ends).
+// Hand-off per stream index i (= block * channels + channel), two 8-byte words, each written by ONE agent-scope store:
+//   size_rec[i]  = 1 << 62 | ms << 61 | bytes     as soon as the plan is final (the data is the flag: R2 granule of
+//                                                 MI355X_MICROARCH.md, no fence needed)
+//   ready_rec[i] = 1  the bitstream is in slot i: the slot is written with write-through (sc1) stores and announced
+//                     behind every storing wave's s_waitcnt vmcnt(0) and the workgroup barrier (cdna_hip_programming.md,
+//                     Guideline 16, R1); the consumer polls relaxed, then fences with an agent-scope acquire before
+//                     it reads the slot;
+//                  2  no bitstream will come from the analysis kernel (left to k_emit).
+// Every wait of the packer is bounded; when it gives up, or for anything it did not move, k_pack / k_emit finish the
+// job after the analysis (they always run), so no dispatch order or co-residency is assumed for correctness.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned long long kRecValid = 1ull << 62, kRecMs = 1ull << 61, kRecBytesMask = (1ull << 61) - 1ull;
+
+__device__ __forceinline__ unsigned long long rec_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rec_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// idx: stream index of this channel block; flag_byte: the block's LR/MS flag byte precedes this channel block.
+template <class G>
+__device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const AnalyzeParams& prm, const FuseArgs& fa,
+                                           const long long idx, const bool flag_byte, const uint32_t flag_value,
+                                           const int tid) {
+    const uint32_t n = th.n;
+    // Optimisation barrier on the thread's coordinates: without it the compiler computes the LDS addresses of the emit
+    // phases at kernel entry and keeps them alive (spilled to scratch) through the whole analysis.
+    asm volatile("" : "+v"(th.tid), "+v"(th.a));
+    const unsigned long long my_size = (unsigned long long)sh.plan.payload_bytes + (flag_byte ? 1u : 0u);
+    // the size is final: publish it at once (the packer can account for this block while it is being emitted)
+    if (tid == 0) rec_store(&fa.size_rec[idx], kRecValid | (flag_value ? kRecMs : 0ull) | my_size);
+    // a bitstream longer than the slot (never seen: it would take > 3 resp. 5 bytes per sample) is left to k_emit;
+    // test hook (LACX_DEBUG_SKIP bit 10): so is every fifth channel block
+    const bool skip = (unsigned long long)sh.plan.payload_bytes + 16u > fa.slot_stride ||
+                      ((prm.debug_skip & 1024u) && (idx % 5 == 3));
+    bool done = false;
+    if (!skip) {  // uniform
+        emit_load_plan(sh, sh.plan, tid, G::T);
+        __syncthreads();
+        emit_first_nonzero(th, sh);
+        const int32_t nxinc = scan_nx_part1<G>(sh, tid, sh.wx);
+        __syncthreads();
+        scan_nx_part2<G>(sh, tid, nxinc, sh.wx, (int32_t)n);
+        __syncthreads();
+        uint8_t* slot = fa.slots + (unsigned long long)idx * fa.slot_stride;
+        done = emit_body<G>(sh, th, n, slot, fa.err_flag, [slot](uint8_t** o) { *o = slot; return true; }, tid,
+                            (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride);
+    }
+    // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
+    // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (done) fa.emitted[idx] = 2u;  // for the kernels that run after this one (k_pack)
+        // test hook (bit 13): the slot is filled but never announced, so the packer gives up and k_pack takes over
+        if (!(prm.debug_skip & 8192u)) rec_store(&fa.ready_rec[idx], done ? 1ull : 2ull);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_analyze
 // ---------------------------------------------------------------------------------------------
@@ -575,7 +787,9 @@ __global__ __launch_bounds__(kLevThreads) void k_levinson(AnalyzeParams prm, con
 template <class G>
 __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const AnalyzeParams& prm, uint32_t n_in,
                                              const SlotSrc& src, int64_t start, const LpcSet* __restrict__ lpc_slot,
-                                             ChannelPlan* __restrict__ plan_out, const int tid) {
+                                             ChannelPlan* __restrict__ plan_out, const int tid, const FuseArgs& fuse,
+                                             const long long fuse_idx, const bool fuse_flag_byte,
+                                             const uint32_t fuse_flag_value) {
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
     const uint32_t n = n_in;
 #ifdef LACX_STAMPS
@@ -784,8 +998,15 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         }
         __syncthreads();
     }
-    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, plan_out);
+    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &sh.plan);
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(ChannelPlan) / 4); i += G::T)
+        reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
     STAMP(21);
+    if constexpr (G::T == 1024) {
+        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid);  // uniform
+    }
+    STAMP(23);
 #if defined(LACX_STAMPS) && LACX_STAMPS == 1
     // one wave per workgroup reports (a different one from workgroup to workgroup): with every wave adding its 24
     // sums to the same addresses the atomics themselves slowed every global load in the kernel down severalfold
@@ -804,7 +1025,7 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans,
                                                   unsigned long long* __restrict__ t_first,
-                                                  unsigned long long* __restrict__ t_last) {
+                                                  unsigned long long* __restrict__ t_last, FuseArgs fuse) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     if (t_first && tid == 0) atomicMin(t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -813,6 +1034,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
     uint32_t blk;
     int slot = -1;
+    int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
+    uint32_t needed_slots = 0;
     if (probe_class) {
         blk = blockIdx.x / 12u;
         const int s = 4 + (int)(blockIdx.x % 12u);
@@ -823,7 +1046,9 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
         xcd_slot(blockIdx.x, per, (prm.debug_skip & 512u) ? 0u : gridDim.x / per, blk, wsel);
         blk += blk_offset;
         int which = (int)wsel + which_base;
+        which_in_block = which;
         uint32_t m = need[blk] & 0xFu;
+        needed_slots = (uint32_t)__popc(m);
         while (m) {
             const int s = __ffs((int)m) - 1;
             if (which == 0) {
@@ -840,7 +1065,18 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
     const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
     const SlotSrc src = slot_src(prm, L, R, slot & 3);
 
-    analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid);
+    // Fused emit: only where the block's channel pair is already final, i.e. exactly `channels` whole-block slots are
+    // needed (a small final block that is encoded both ways and compared afterwards is left to k_emit).
+    long long fuse_idx = -1;
+    bool flag_byte = false;
+    if (fuse.slots && !probe_class) {
+        fuse_idx = (long long)prm.stream_base + ((long long)blk - (long long)blk_offset) * prm.channels + which_in_block;
+        flag_byte = prm.channels == 2 && prm.stereo_mode == 2 && which_in_block == 0;
+        // the host excludes a small final block that may be encoded both ways and compared afterwards (fuse_items)
+        if (fuse_idx >= (long long)fuse.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
+    }
+    analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid, fuse, fuse_idx, flag_byte,
+                    (uint32_t)((slot & 3) >= 2 ? 1u : 0u));
     if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
@@ -921,47 +1157,16 @@ __global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const Block
     if (tid == 1023) block_off[nb] = base + inc;
 }
 
-// suffix-min scan of tabNX (first non-zero index per chunk) -> exclusive: min over later chunks
+// One channel block of k_emit (workgroup-uniform control flow throughout).
 template <class G>
-__device__ __forceinline__ int32_t scan_nx_part1(EmitMem<G>& sh, int tid, int32_t* wtot) {
-    const int lane = tid & 63, wave = tid >> 6;
-    int32_t v = sh.tabNX[tid];
-    int32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int32_t o = __shfl_down(inc, d, 64);
-        if (lane + d < 64) inc = o < inc ? o : inc;
-    }
-    if (lane == 0) wtot[wave] = inc;
-    return inc;
-}
-
-template <class G>
-__device__ __forceinline__ void scan_nx_part2(EmitMem<G>& sh, int tid, int32_t inc, const int32_t* wtot, int32_t n) {
-    constexpr int NW = G::T / 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    int32_t later = n;
-    for (int w = wave + 1; w < NW; ++w) later = wtot[w] < later ? wtot[w] : later;
-    int32_t next = __shfl_down(inc, 1, 64);
-    if (lane == 63) next = n;
-    sh.tabNX[tid] = next < later ? next : later;
-}
-
-template <class G>
-__global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
-                                               AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
-                                               const ChannelPlan* __restrict__ plans,
-                                               const unsigned long long* __restrict__ block_off,
-                                               uint8_t* __restrict__ out, unsigned long long out_cap,
-                                               uint32_t* __restrict__ err_flag) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
-    __shared__ int32_t s_wx[16];
-    const int tid = threadIdx.x;
-    const uint32_t per = prm.channels == 2 ? 2u : 1u;
-    uint32_t blk, wsel;
-    xcd_slot(blockIdx.x, per, gridDim.x / per, blk, wsel);
-    const int which = (int)wsel;
+__device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx, const int32_t* __restrict__ L,
+                                                   const int32_t* __restrict__ R, const AnalyzeParams& prm,
+                                                   const BlockPlan* __restrict__ bplans,
+                                                   const ChannelPlan* __restrict__ plans,
+                                                   const unsigned long long* __restrict__ block_off,
+                                                   uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                   uint32_t* __restrict__ err_flag, uint32_t blk, int which, int tid) {
+    asm volatile("" : "+v"(tid));  // nothing derived from the thread index is hoisted out of the caller's loop (spills)
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
     const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
@@ -977,134 +1182,202 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     }
     if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
 
-#if defined(LACX_STAMPS) && LACX_STAMPS == 2
-    unsigned long long estamp_acc[24];
-    for (int k = 0; k < 24; ++k) estamp_acc[k] = 0;
-    unsigned long long estamp_prev = __builtin_amdgcn_s_memtime();
-    const unsigned long long estamp_rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     Thread<G> th;
     thread_init(th, n, tid);
     stage_samples(th, sh, slot_src(prm, L, R, kind), (int64_t)blk * kMaxBlock);
-    ESTAMP(0);
     emit_load_plan(sh, *plan, tid, G::T);
     if (tid == 0 && !plan->valid) sh.err = 1;
     __syncthreads();
-    ESTAMP(1);
     phase_r(th, sh, (int)sh.cand);
     emit_first_nonzero(th, sh);
-    ESTAMP(2);
     ScanRegs<G> sr;
     scan_pz_part1<G>(sh, tid, sr);
-    const int32_t nxinc = scan_nx_part1(sh, tid, s_wx);
+    const int32_t nxinc = scan_nx_part1<G>(sh, tid, s_wx);
     __syncthreads();
     scan_pz_part2<G>(sh, tid, sr);
-    scan_nx_part2(sh, tid, nxinc, s_wx, (int32_t)n);
+    scan_nx_part2<G>(sh, tid, nxinc, s_wx, (int32_t)n);
     __syncthreads();
-    ESTAMP(3);
-    const bool narrow = sh.tabP[G::T] < (1ull << 31);
-    const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
-    if (adaptive0) {
-        if (narrow) {
-            phase_a<G, true>(th, sh);
-        } else {
-            phase_a<G, false>(th, sh);
-        }
-        __syncthreads();
-    }
-    ESTAMP(4);
-    auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
-    auto stw = [](uint32_t* w, uint32_t v) { *w = v; };
-    // walk 1: Rice parameter per sample + token bits of the chunk
-    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw, stw)
-                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw, stw);
-    ESTAMP(5);
-    __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
-    ESTAMP(6);
-    sh.tabP[tid] = mybits;
-    {
-        // sum scan of the bit counts (tabP only)
-        const int lane = tid & 63, wave = tid >> 6;
-        const unsigned long long inc = wave_scan_add_u64(mybits);
-        if (lane == 63) sh.wtotP[wave] = inc;
-        __syncthreads();
-        unsigned long long base = 0;
-        for (int w = 0; w < wave; ++w) base += sh.wtotP[w];
-        sh.tabP[tid] = base + inc - mybits;
-        if (tid == G::T - 1) sh.tabP[G::T] = base + inc;
-        __syncthreads();
-    }
-    const unsigned long long total_bits = sh.tabP[G::T] + sh.header_bits;
-    const unsigned long long nbytes = (total_bits + 7u) >> 3;
-    if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
-    if (nbytes != sh.payload_bytes || sh.err) return;  // uniform: never write outside the planned byte range
-    const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
-    ESTAMP(7);
+    emit_body<G>(sh, th, n, out, err_flag, [out, off](uint8_t** o) { *o = out + off; return true; }, tid);
+}
 
-    // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
-    for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
-        for (int i = tid; i < kEmitTileWords; i += G::T) sh.xp.o.obits[i] = 0;
-        __syncthreads();
-        ESTAMP(8);
-        BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
-        if (bit0 == 0) emit_header(th, sh, &tile, orw);
-        const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
-        if (mypos < tile_end && mypos + mybits > bit0) {
-            if (narrow) {
-                emit_walk<G, true>(th, sh, &tile, mypos, orw, stw);
-            } else {
-                emit_walk<G, false>(th, sh, &tile, mypos, orw, stw);
-            }
-        }
-        ESTAMP(9);
-        __syncthreads();
-        ESTAMP(10);
-        const unsigned long long byte0 = bit0 >> 3;
-        const unsigned long long left = nbytes - byte0;
-        const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
-        // Copy-out in 16-byte stores on 16-byte boundaries of the destination (which may be pinned host
-        // memory behind PCIe: whole, aligned segments matter there); the unaligned head and tail go bytewise.
-        uint8_t* dst = out + off + byte0;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
-        const uint32_t head = mis ? (16u - mis < count ? 16u - mis : count) : 0u;
-        const uint32_t nvec = (count - head) >> 4;
-        const uint32_t* tw = sh.xp.o.obits;
-        auto tile_byte = [&](uint32_t i) { return (uint8_t)(tw[i >> 2] >> (24u - 8u * (i & 3u))); };
-        if ((uint32_t)tid < head) dst[tid] = tile_byte((uint32_t)tid);
-        {
-            const uint32_t r = head & 3u, j0 = head >> 2;
-            uint4* vdst = reinterpret_cast<uint4*>(dst + head);
-            for (uint32_t v = tid; v < nvec; v += G::T) {
-                const uint32_t j = j0 + 4u * v;
-                uint32_t w[5];
+// k_emit: the bitstream of every channel block of the chunk that the fused emit has not produced (emitted[] == 0;
+// all of them when emitted is null).  With a full grid every workgroup handles one channel block (XCD-aware mapping as
+// in k_analyze); behind the fused emit the launcher uses a small grid that strides over the chunk, because then there
+// is normally nothing left to do and a full grid of 1024-thread workgroups that exit at once is pure launch time.
+template <class G>
+__global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
+                                               AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+                                               const ChannelPlan* __restrict__ plans,
+                                               const unsigned long long* __restrict__ block_off,
+                                               uint8_t* __restrict__ out, unsigned long long out_cap,
+                                               uint32_t* __restrict__ err_flag,
+                                               const uint32_t* __restrict__ emitted) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
+    __shared__ int32_t s_wx[16];
+    const int tid = threadIdx.x;
+    const uint32_t per = prm.channels == 2 ? 2u : 1u;
+    const uint32_t total = prm.num_blocks * per;
+    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+        uint32_t blk, wsel;
+        xcd_slot(w, per, gridDim.x == total ? total / per : 0u, blk, wsel);
+        if (emitted && emitted[(size_t)prm.stream_base + (size_t)blk * per + wsel]) continue;  // uniform
+        emit_channel_block<G>(sh, s_wx, L, R, prm, bplans, plans, block_off, out, out_cap, err_flag, blk, (int)wsel, tid);
+        __syncthreads();  // the LDS image is reused by the next channel block
+    }
+}
+
+// `count` bytes from a staging slot (16-byte aligned, padded by 16 readable bytes) to dst (any alignment): 16-byte
+// stores on 16-byte boundaries of the destination, the ragged head and tail bytewise.  One 256-thread workgroup.
+constexpr int kPackThreads = 256;
+__device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t count,
+                                              int tid) {
+    const uint32_t* sw32 = reinterpret_cast<const uint32_t*>(src);
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+    const uint32_t head = mis ? (16u - mis < count ? 16u - mis : count) : 0u;
+    const uint32_t nvec = (count - head) >> 4;
+    if ((uint32_t)tid < head) dst[tid] = src[tid];
+    {
+        const uint32_t r = head & 3u, j0 = head >> 2;
+        uint4* vdst = reinterpret_cast<uint4*>(dst + head);
+        for (uint32_t v = tid; v < nvec; v += kPackThreads) {
+            const uint32_t j = j0 + 4u * v;
+            uint32_t w[5];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const uint32_t jj = j + q < (uint32_t)kEmitTileWords ? j + q : (uint32_t)kEmitTileWords - 1u;
-                    w[q] = __builtin_bswap32(tw[jj]);  // bytes of the stream in memory order
+            for (int q = 0; q < 5; ++q) w[q] = sw32[j + q];  // j + 4 stays inside the slot's padding
+            uint4 o;
+            o.x = __builtin_amdgcn_alignbyte(w[1], w[0], r);
+            o.y = __builtin_amdgcn_alignbyte(w[2], w[1], r);
+            o.z = __builtin_amdgcn_alignbyte(w[3], w[2], r);
+            o.w = __builtin_amdgcn_alignbyte(w[4], w[3], r);
+            vdst[v] = o;
+        }
+    }
+    const uint32_t t0 = head + (nvec << 4);
+    if (t0 + (uint32_t)tid < count) dst[t0 + tid] = src[t0 + tid];
+}
+
+// k_stream_out: the streaming packer (see "Fused emit + streaming packer" above).  kStreamGrid workgroups; workgroup w
+// moves the stream indices w, w + grid, ...; each keeps its own running byte offset by summing the size records of
+// every index in order (64 per load round).  total: number of fusable stream indices of the shard.
+constexpr int kStreamGrid = 8;  // measured: more workgroups keep more PCIe writes in flight and slow the analysis kernel down
+constexpr unsigned long long kStreamTimeoutTicks = 2000000ull;  // 20 ms of the 100 MHz clock without the awaited record
+__global__ __launch_bounds__(kPackThreads) void k_stream_out(uint32_t total, int autost, int nap,
+                                                             const unsigned long long* __restrict__ size_rec,
+                                                             const unsigned long long* __restrict__ ready_rec,
+                                                             const uint8_t* __restrict__ slots, unsigned long long slot_stride,
+                                                             uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                             uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag) {
+    __shared__ unsigned long long s_off, s_rec;
+    __shared__ uint32_t s_state;  // 1 copy, 2 nothing to copy, 3 give up
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned long long running = 0;  // bytes of the stream indices [0, summed)   (wave 0 only)
+    uint32_t summed = 0;
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        if (tid < 64) {  // wave 0, all lanes
+            bool alive = true;
+            unsigned long long mine = 0;
+            // sizes of [summed, i], 64 records per round; the last one is this index's own
+            while (alive && summed <= i) {
+                const uint32_t j = summed + (uint32_t)lane;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long v;
+                for (;;) {
+                    v = (j <= i) ? rec_load(&size_rec[j]) : kRecValid;
+                    if (__ballot((v & kRecValid) == 0ull) == 0ull) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
+                        alive = false;
+                        break;
+                    }
+                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
                 }
-                uint4 o;
-                o.x = __builtin_amdgcn_alignbyte(w[1], w[0], r);
-                o.y = __builtin_amdgcn_alignbyte(w[2], w[1], r);
-                o.z = __builtin_amdgcn_alignbyte(w[3], w[2], r);
-                o.w = __builtin_amdgcn_alignbyte(w[4], w[3], r);
-                vdst[v] = o;
+                if (!alive) break;
+                const uint32_t cnt = (i - summed + 1u) < 64u ? (i - summed + 1u) : 64u;
+                const bool last_round = summed + cnt == i + 1u;
+                // everything but this index's own record goes into the running offset
+                const bool take = (uint32_t)lane < cnt && !(last_round && (uint32_t)lane == cnt - 1u);
+                running += wave_sum_u64(take ? (v & kRecBytesMask) : 0ull);
+                if (last_round) mine = __shfl(v, (int)cnt - 1, 64);
+                summed += cnt;
+            }
+            unsigned long long ready = 0;
+            if (alive) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    ready = rec_load(&ready_rec[i]);
+                    if (ready != 0ull) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
+                        alive = false;
+                        break;
+                    }
+                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            if (alive && ready == 1ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid == 0) {
+                s_state = !alive ? 3u : (ready == 1ull ? 1u : 2u);
+                s_off = running;
+                s_rec = mine;
+            }
+            running += mine & kRecBytesMask;  // this index is accounted for whatever happens to its bytes
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier releases
+        }
+        __syncthreads();
+        const uint32_t state = s_state;
+        if (state == 3u) break;  // uniform: a producer went missing; k_pack / k_emit move what is left
+        if (state == 1u) {
+            const unsigned long long rec = s_rec, off = s_off;
+            const unsigned long long bytes = rec & kRecBytesMask;
+            const bool flag_byte = autost && (i & 1u) == 0u;
+            if (off + bytes > out_cap) {  // the destination was sized from an estimate: report, write nothing
+                if (tid == 0) atomicOr(err_flag, 2u);
+            } else {
+                if (flag_byte && tid == 0) out[off] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+                const uint32_t fb = flag_byte ? 1u : 0u;
+                copy_slot_out(slots + (unsigned long long)i * slot_stride, out + off + fb, (uint32_t)bytes - fb, tid);
+                if (tid == 0) packed[i] = 1u;
             }
         }
-        {
-            const uint32_t t0 = head + (nvec << 4);
-            if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
-        }
-        ESTAMP(11);
         __syncthreads();
-        ESTAMP(12);
     }
-#if defined(LACX_STAMPS) && LACX_STAMPS == 2
-    if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u)) {  // one wave per workgroup, see k_analyze
-        estamp_acc[22] = __builtin_amdgcn_s_memrealtime() - estamp_rt0;
-        for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], estamp_acc[k]);
-        atomicAdd(&g_stamp_acc[24], 1ull);
+}
+
+// k_pack: copies the channel blocks that the fused emit has written to their staging slots to their place in the shard
+// payload (usually pinned host memory behind PCIe), in 16-byte stores on 16-byte boundaries of the destination; the
+// ragged head and tail go bytewise.  Pure data movement at the pace of the PCIe link, so the grid is deliberately
+// small (kPackGrid workgroups striding over the channel blocks): a grid of one workgroup per channel block would fill
+// every wave slot of the chip with waves that wait for PCIe and lock the next chunk's analysis kernel out.
+constexpr int kPackGrid = 96;
+__global__ __launch_bounds__(kPackThreads) void k_pack(AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+                                                       const ChannelPlan* __restrict__ plans,
+                                                       const unsigned long long* __restrict__ block_off,
+                                                       uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                       uint32_t* __restrict__ err_flag, const uint8_t* __restrict__ slots,
+                                                       unsigned long long slot_stride,
+                                                       const uint32_t* __restrict__ emitted,
+                                                       const uint32_t* __restrict__ packed) {
+    const int tid = threadIdx.x;
+    const uint32_t per = prm.channels == 2 ? 2u : 1u;
+    for (uint32_t work = blockIdx.x; work < prm.num_blocks * per; work += gridDim.x) {
+    const uint32_t blk = work / per;
+    const int which = (int)(work % per);
+    const size_t idx = (size_t)prm.stream_base + work;
+    if (emitted[idx] != 2u || (packed && packed[idx])) continue;  // not in its slot (k_emit's job) / moved by the packer
+    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
+    const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
+    const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
+    const int kind = which == 0 ? first_kind : (ms ? CH_S : CH_R);
+    const uint32_t count = plans[(size_t)blk * kSlotsPerBlock + kind].payload_bytes;
+    unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
+    if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
+    // the destination is sized from an estimate: if this block does not fit, report it and write nothing
+    if (block_off[blk + 1] > out_cap) {
+        if (tid == 0) atomicOr(err_flag, 2u);
+        continue;
     }
-#endif
+    if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+    copy_slot_out(slots + idx * slot_stride, out + off, count, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1160,7 +1433,7 @@ static hipError_t ensure_kernel_attrs() {
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                        const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
-                       hipEvent_t offsets_done, hipStream_t stream) {
+                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted) {
     const hipError_t attr_err = ensure_kernel_attrs();
     if (attr_err != hipSuccess) return attr_err;
     const uint32_t nb = prm.num_blocks;
@@ -1175,14 +1448,37 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
         const hipError_t re = hipEventRecord(offsets_done, stream);
         if (re != hipSuccess) return re;
     }
-    hipLaunchKernelGGL(k_emit<GFull>, dim3(nb * (prm.channels == 2 ? 2u : 1u)), dim3(GFull::T),
+    if (skip_emitted && ws.slots) {
+        const uint32_t work = nb * (prm.channels == 2 ? 2u : 1u);
+        hipLaunchKernelGGL(k_pack, dim3(work < (uint32_t)kPackGrid ? work : (uint32_t)kPackGrid), dim3(kPackThreads), 0, stream, prm, ws.bplans,
+                           ws.plans, ws.block_off, out, out_cap, ws.err_flag, (const uint8_t*)ws.slots, ws.slot_stride,
+                           (const uint32_t*)ws.emitted, (const uint32_t*)ws.packed);
+    }
+    const uint32_t emit_work = nb * (prm.channels == 2 ? 2u : 1u);
+    const bool leftovers_only = skip_emitted && ws.slots;  // behind the fused emit
+    hipLaunchKernelGGL(k_emit<GFull>, dim3(leftovers_only && emit_work > 64u ? 64u : emit_work), dim3(GFull::T),
                        sizeof(EmitMem<GFull>), stream, d_left, d_right, prm, ws.bplans, ws.plans, ws.block_off,
-                       out, out_cap, ws.err_flag);
+                       out, out_cap, ws.err_flag, skip_emitted ? (const uint32_t*)ws.emitted : (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
+                             unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream) {
+    if (fuse_items == 0) return hipSuccess;
+    int nap = 1, grid = kStreamGrid;  // tuning knobs
+    if (const char* v = std::getenv("LACX_PACK_NAP")) nap = std::atoi(v) > 0 ? std::atoi(v) : 1;
+    if (const char* v = std::getenv("LACX_PACK_GRID")) grid = std::atoi(v) > 0 ? std::atoi(v) : grid;
+    hipLaunchKernelGGL(k_stream_out, dim3(fuse_items < (uint32_t)grid ? fuse_items : (uint32_t)grid),
+                       dim3(kPackThreads), 0, stream, fuse_items, autost, nap, (const unsigned long long*)ws.size_rec,
+                       (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots, ws.slot_stride, out, out_cap,
+                       ws.packed, err_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev) {
+                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev, const FuseArgs* fuse,
+                           hipEvent_t wait_before_full) {
+    const FuseArgs fa = fuse ? *fuse : FuseArgs{};
     hipError_t e = ensure_kernel_attrs();
     if (e != hipSuccess) return e;
     const uint32_t nb = prm.num_blocks;
@@ -1201,21 +1497,25 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     if (autost) {
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
                            d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr,
-                           (unsigned long long*)nullptr);
+                           (unsigned long long*)nullptr, FuseArgs{});
         hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
+    if (wait_before_full) {
+        const hipError_t we = hipStreamWaitEvent(stream, wait_before_full, 0);
+        if (we != hipSuccess) return we;
+    }
     const uint32_t per = prm.channels == 2 ? 2u : 1u;
     hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * per), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left,
-                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last);
+                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa);
     // Only a final block of <= 4096 frames can need all four channels (full LR-vs-MS comparison,
     // ref lac/encoder.cpp:336-340): its 3rd and 4th slots go in a two-workgroup launch.
     const uint64_t last_frames = prm.frames - (uint64_t)(nb - 1) * kMaxBlock;
     if (autost && last_frames <= (uint64_t)kFullCompareLimit) {
         hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left, d_right,
                            prm, 0, nb - 1, 2, ws.lpcs, ws.need_full, ws.plans, (unsigned long long*)nullptr,
-                           (unsigned long long*)nullptr);
+                           (unsigned long long*)nullptr, FuseArgs{});
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (autost) {

@@ -64,6 +64,7 @@ struct lacx_encoder {
         uint32_t nb = 0;
         int channels = 0;
         bool staged = false;
+        bool fused = false;
         hipStream_t st[4] = {};
         clk::time_point t0;
         // inputs of the call, kept for the re-emit after a too-small result reservation
@@ -73,6 +74,10 @@ struct lacx_encoder {
         int layout = 0;
     } pend;
     hipEvent_t prologue = nullptr;  // per-call memsets done (the chunk streams wait for it)
+    hipStream_t pack_stream = nullptr;  // the streaming packer of the fused emit runs here, beside the analysis
+    hipEvent_t pack_done = nullptr;
+    uint8_t* slots = nullptr;  // staging slots of the fused emit (device memory)
+    unsigned long long slots_cap = 0;
     uint8_t* d_raw = nullptr;  // WAV data chunk as read from the file (lacx_encode_wav)
     uint64_t d_raw_cap = 0;
     uint8_t* h_payload = nullptr;  // pinned
@@ -80,6 +85,8 @@ struct lacx_encoder {
     uint32_t* h_table = nullptr;   // pinned, [blocks][2]
     unsigned long long* h_totals = nullptr;  // pinned, per chunk payload bytes
     uint32_t* h_err = nullptr;     // pinned, per chunk
+    uint32_t* h_emitted = nullptr; // pinned copy of ws.emitted (statistics of the fused emit)
+    uint32_t h_emitted_cap = 0;
     unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: first-start / last-end device clock of k_analyze<16,1024>
     unsigned long long* h_tspan = nullptr;  // pinned copy
     uint32_t h_table_blocks = 0;
@@ -164,7 +171,13 @@ int ensure_device(lacx_encoder* e) {
     for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipEventCreateWithFlags(&e->prologue, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
-    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * kMaxChunks, 0), "hipHostMalloc");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 1), 0), "hipHostMalloc");
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->pack_stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
+    }
+    HIP_TRY(e, hipEventCreateWithFlags(&e->pack_done, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipMalloc((void**)&e->d_tspan, sizeof(unsigned long long) * 2 * kMaxChunks), "hipMalloc(tspan)");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_tspan, sizeof(unsigned long long) * 2 * kMaxChunks, 0), "hipHostMalloc");
     e->device_ready = true;
@@ -192,6 +205,9 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.block_off) (void)hipFree(e->ws.block_off);
     if (e->ws.table) (void)hipFree(e->ws.table);
     if (e->ws.err_flag) (void)hipFree(e->ws.err_flag);
+    if (e->ws.emitted) (void)hipFree(e->ws.emitted);
+    if (e->ws.packed) (void)hipFree(e->ws.packed);
+    if (e->ws.size_rec) (void)hipFree(e->ws.size_rec);
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -211,7 +227,14 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
                 "hipMalloc(block_off)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
-        HIP_TRY(e, hipMalloc((void**)&e->ws.err_flag, sizeof(uint32_t) * kMaxChunks), "hipMalloc(err)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.err_flag, sizeof(uint32_t) * (kMaxChunks + 1)), "hipMalloc(err)");
+        // fused emit: one flag per channel block of the shard (the staging slots are sized per call, ensure_slots)
+        HIP_TRY(e, hipMalloc((void**)&e->ws.emitted, ((size_t)nblocks * 2 + 4) * sizeof(uint32_t)), "hipMalloc(emitted)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.packed, ((size_t)nblocks * 2 + 4) * sizeof(uint32_t)), "hipMalloc(packed)");
+        // size records and ready records of the fused emit, one allocation (zeroed together before every call)
+        HIP_TRY(e, hipMalloc((void**)&e->ws.size_rec, ((size_t)nblocks * 4 + 4) * sizeof(unsigned long long)),
+                "hipMalloc(hand-off records)");
+        e->ws.ready_rec = e->ws.size_rec + ((size_t)nblocks * 2 + 2);
         e->ws_blocks = nblocks;
     }
     if (nblocks > e->h_blocks) {
@@ -226,6 +249,25 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
                 "hipHostMalloc(bplans)");
         e->h_blocks = nblocks;
     }
+    return LACX_OK;
+}
+
+// Staging slots of the fused emit: one per channel block, fixed stride.  3 bytes per sample cover any 16-bit material
+// and 5 any 24-bit material with room to spare (raw PCM is 2 resp. 3; the costliest constructible streams stay under
+// 1.2 x raw); a longer bitstream simply falls back to k_emit.  Device memory only: 48 KiB per channel block of 16-bit
+// audio (a 2 h stereo shard: 2 GB of the 288 GB).
+int ensure_slots(lacx_encoder* e, uint32_t nblocks, int channels) {
+    const unsigned long long stride = (unsigned long long)kMaxBlock * (e->cfg.bit_depth == 16 ? 3u : 5u);
+    const unsigned long long need = stride * nblocks * (unsigned)channels + 64u;
+    if (need > e->slots_cap) {
+        if (e->slots) (void)hipFree(e->slots);
+        e->slots = nullptr;
+        e->slots_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->slots, need), "hipMalloc(emit slots)");
+        e->slots_cap = need;
+    }
+    e->ws.slots = e->slots;
+    e->ws.slot_stride = stride;
     return LACX_OK;
 }
 
@@ -293,10 +335,13 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
 // Host emit wants many chunks (emit of chunk i overlaps the analysis of chunk i+1); with the emit on the
 // device the only host work is a copy, and two chunks (payload copy of one under the kernels of the other)
 // measured best.
-std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false) {
+std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused = false) {
     uint32_t nchunks = nb / kMinChunkBlocks;
-    // device emit: 3 chunks up to an hour of stereo 48 kHz per call, 4 and 6 beyond (measured on a 2 h shard)
-    const uint32_t dev_chunks = nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u);
+    // device emit without the fused path: 3 chunks up to an hour of stereo 48 kHz per call, 4 and 6 beyond (measured on a
+    // 2 h shard).  With the fused emit + streaming packer nothing is left to overlap by chunking -- the payload leaves
+    // while the analysis runs, and ingest / probes keep every CU busy by themselves -- and one launch set measured best
+    // from 10 min to 2 h of audio (a chunked run only adds kernel boundaries).
+    const uint32_t dev_chunks = fused ? 1u : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
     nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
@@ -566,6 +611,7 @@ ChunkCtx chunk_ctx(lacx_encoder* e, const int32_t* d_left, const int32_t* d_righ
     const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
     const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
     x.prm = make_params(e, f1 - f0, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
+    x.prm.stream_base = ck.first * (uint32_t)channels;
     // chunk base pointers: planar int32 advances by frames, interleaved layouts by bytes
     x.left = layout ? reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(d_left) + f0 * frame_bytes)
                     : d_left + f0;
@@ -597,7 +643,11 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     const uint32_t nb = blocks_for(frames);
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
-    e->pend.chunks = plan_chunks(nb, true);
+    // Emit fused into the analysis kernel (default; LACX_FUSED_EMIT=0 leaves the bitstream to k_offsets + k_emit alone;
+    // k_emit runs after the analysis in any case and picks up whatever the fused path did not write).
+    const char* fenv = std::getenv("LACX_FUSED_EMIT");
+    const bool fused = !(fenv && *fenv == '0');
+    e->pend.chunks = plan_chunks(nb, true, fused);
     const std::vector<Chunk>& chunks = e->pend.chunks;
     // Destination of k_emit: by default the pinned host buffer itself (the kernel's 16-byte stores cross PCIe
     // while later blocks are still being analysed, so no separate D2H pass is left at the end); with
@@ -643,10 +693,34 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         emit_cap = e->h_payload_cap;
     }
     const unsigned long long* prev_end = nullptr;  // device address of the byte total of the chunks so far
-    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * (kMaxChunks + 1), st[0]), "memset");
     HIP_TRY(e, hipMemsetAsync(e->d_tspan, 0xFF, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
     HIP_TRY(e, hipMemsetAsync(e->d_tspan + kMaxChunks, 0, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
+    if (fused) {
+        rc = ensure_slots(e, nb, channels);
+        if (rc) return rc;
+        if (nb * 2u > e->h_emitted_cap) {
+            if (e->h_emitted) (void)hipHostFree(e->h_emitted);
+            e->h_emitted = nullptr;
+            e->h_emitted_cap = 0;
+            HIP_TRY(e, hipHostMalloc((void**)&e->h_emitted, (size_t)nb * 2 * sizeof(uint32_t), 0), "hipHostMalloc(emitted)");
+            e->h_emitted_cap = nb * 2u;
+        }
+    } else {
+        e->ws.slots = nullptr;
+    }
+    HIP_TRY(e, hipMemsetAsync(e->ws.emitted, 0, ((size_t)nb * 2 + 4) * sizeof(uint32_t), st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->ws.packed, 0, ((size_t)nb * 2 + 4) * sizeof(uint32_t), st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->ws.size_rec, 0, ((size_t)nb * 4 + 4) * sizeof(unsigned long long), st[0]), "memset");
     HIP_TRY(e, hipEventRecord(e->prologue, st[0]), "event record");
+    // Stream indices that take part in the fused emit: all but those of a final block of <= 4096 frames in per-block
+    // stereo mode, which may be encoded both ways and compared afterwards (ref lac/encoder.cpp:336-340).
+    uint32_t fuse_items = 0;
+    if (fused) {
+        const uint64_t last_frames = frames - (uint64_t)(nb - 1) * kMaxBlock;
+        const bool last_both_ways = channels == 2 && e->cfg.stereo_mode == 2 && last_frames <= (uint64_t)kFullCompareLimit;
+        fuse_items = (nb - (last_both_ways ? 1u : 0u)) * (uint32_t)channels;
+    }
     for (size_t c = 0; c < chunks.size(); ++c) {
         const Chunk& ck = chunks[c];
         hipStream_t s = st[c % kStreams];
@@ -655,7 +729,40 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         const AnalyzeParams& prm = cx.prm;
         const int32_t *cl = cx.left, *cr = cx.right;
         const DeviceWorkspace& w = cx.w;
-        HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c]), "kernel launch");
+        FuseArgs fa;
+        if (fused) {
+            fa.slots = e->ws.slots;
+            fa.slot_stride = e->ws.slot_stride;
+            fa.emitted = e->ws.emitted;
+            fa.err_flag = w.err_flag;
+            fa.size_rec = e->ws.size_rec;
+            fa.ready_rec = e->ws.ready_rec;
+            fa.fuse_items = fuse_items;
+        }
+        // Fused emit: the packer walks the stream indices in order, so the whole-block kernels of the chunks run in that
+        // order too (chunk c's waits for chunk c-1's: ev[c-1][3] is recorded behind it); what comes before them --
+        // ingest, Levinson, probes -- still overlaps the previous chunk's analysis.
+        const bool chain = fused && c > 0 && !std::getenv("LACX_NO_CHAIN");
+        HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
+        if (c == 0 && fuse_items && !std::getenv("LACX_NO_PACKER")) {
+            // the streaming packer: beside the analysis kernels, on its own stream, from the first chunk's analysis on
+            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->prologue, 0), "stream wait");
+            HIP_TRY(e, launch_stream_out(fuse_items, (channels == 2 && e->cfg.stereo_mode == 2) ? 1 : 0, e->ws, emit_dst,
+                                         emit_cap, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
+            HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
+        }
+    }
+    // Second pass over the chunks: everything behind the analysis.  With the fused emit it waits for the packer (what
+    // k_pack / k_emit still have to move is only known once the packer has finished), and a stream may carry several
+    // chunks, so none of this may be enqueued before the last chunk's analysis kernels.
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        const Chunk& ck = chunks[c];
+        hipStream_t s = st[c % kStreams];
+        const ChunkCtx cx = chunk_ctx(e, d_left, d_right, frames, layout, channels, ck, c);
+        const AnalyzeParams& prm = cx.prm;
+        const int32_t *cl = cx.left, *cr = cx.right;
+        const DeviceWorkspace& w = cx.w;
+        if (fuse_items && !std::getenv("LACX_NO_PACKER")) HIP_TRY(e, hipStreamWaitEvent(s, e->pack_done, 0), "stream wait");
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
         HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
                                e->copied[c], s), "emit launch");
@@ -668,6 +775,12 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         HIP_TRY(e, hipMemcpyAsync(&e->h_totals[c], w.block_off + ck.count, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, s), "D2H total");
         HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
+        if (c + 1 == chunks.size())
+            HIP_TRY(e, hipMemcpyAsync(&e->h_err[kMaxChunks], e->ws.err_flag + kMaxChunks, sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, s), "D2H err");
+        if (fused)
+            HIP_TRY(e, hipMemcpyAsync(e->h_emitted + (size_t)ck.first * channels, e->ws.packed + (size_t)ck.first * channels,
+                                      (size_t)ck.count * channels * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H packed");
         HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[c], w.t_first, sizeof(unsigned long long), hipMemcpyDeviceToHost, s), "D2H t");
         HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[kMaxChunks + c], w.t_last, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, s), "D2H t");
@@ -677,6 +790,7 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     e->pend.nb = nb;
     e->pend.channels = channels;
     e->pend.staged = staged;
+    e->pend.fused = fused;
     for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
     e->pend.t0 = t0;
     e->pend.d_left = d_left;
@@ -702,12 +816,13 @@ int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size) {
     uint8_t* dst = nullptr;
     HIP_TRY(e, hipHostGetDevicePointer((void**)&dst, e->h_payload, 0), "hipHostGetDevicePointer");
     hipStream_t s = e->stream[0];
-    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * kMaxChunks, s), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * (kMaxChunks + 1), s), "memset");
     const unsigned long long* prev_end = nullptr;
     for (size_t c = 0; c < chunks.size(); ++c) {
         const ChunkCtx cx = chunk_ctx(e, e->pend.d_left, e->pend.d_right, e->pend.frames, e->pend.layout,
                                       e->pend.channels, chunks[c], c);
-        HIP_TRY(e, launch_emit(cx.left, cx.right, cx.prm, cx.w, dst, cap, prev_end, nullptr, nullptr, s), "emit relaunch");
+        HIP_TRY(e, launch_emit(cx.left, cx.right, cx.prm, cx.w, dst, cap, prev_end, nullptr, nullptr, s,
+                               /*skip_emitted=*/false), "emit relaunch");
         prev_end = cx.w.block_off + chunks[c].count;
         HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], cx.w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
     }
@@ -753,7 +868,8 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
             break;
         }
         const uint64_t end = e->h_totals[c];  // cumulative
-        if ((e->h_err[c] & 2u) || end > e->h_payload_cap) {
+        const bool packer_overflow = c + 1 == chunks.size() && (e->h_err[kMaxChunks] & 2u);
+        if ((e->h_err[c] & 2u) || packer_overflow || end > e->h_payload_cap) {
             status = -1;  // reservation too small: re-emit into a regrown buffer below
             break;
         }
@@ -797,6 +913,10 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     }
     e->timing.full_launches = (uint32_t)chunks.size();
     e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
+    e->timing.emit_direct = e->timing.emit_parked = 0;
+    if (e->pend.fused) {
+        for (size_t i = 0; i < (size_t)nb * (size_t)channels; ++i) e->timing.emit_direct += e->h_emitted[i] == 1u;
+    }
     e->timing.full_exec_ms = 0;
     for (size_t c = 0; c < chunks.size(); ++c) {
         const unsigned long long a = e->h_tspan[c], b = e->h_tspan[kMaxChunks + c];
@@ -901,12 +1021,16 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         for (auto& ev : e->copied)
             if (ev) (void)hipEventDestroy(ev);
         if (e->prologue) (void)hipEventDestroy(e->prologue);
+        if (e->pack_done) (void)hipEventDestroy(e->pack_done);
+        if (e->pack_stream) (void)hipStreamDestroy(e->pack_stream);
         if (e->d_payload) (void)hipFree(e->d_payload);
+        if (e->slots) (void)hipFree(e->slots);
         if (e->d_raw) (void)hipFree(e->d_raw);
         if (e->h_payload) (void)hipHostFree(e->h_payload);
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
         if (e->h_err) (void)hipHostFree(e->h_err);
+        if (e->h_emitted) (void)hipHostFree(e->h_emitted);
         if (e->h_tspan) (void)hipHostFree(e->h_tspan);
         if (e->d_tspan) (void)hipFree(e->d_tspan);
         for (auto& s : e->stream)

@@ -61,6 +61,7 @@ struct AnalyzeParams {
     int32_t partitioning;
     uint32_t debug_skip;   // diagnostic ablation mask (timing experiments only; 0 in production)
     int32_t layout;        // PCM_PLANAR_I32 / PCM_INTERLEAVED_I16 / PCM_INTERLEAVED_I24 (analyze_core.h)
+    uint32_t stream_base;  // fused emit: stream index (block * channels + channel) of the chunk's first channel block
 };
 
 }  // namespace lacx

@@ -78,6 +78,8 @@ class Timing(C.Structure):
         ("full_launches", C.c_uint32),
         ("regrows", C.c_uint32),
         ("full_exec_ms", C.c_double),
+        ("emit_direct", C.c_uint32),
+        ("emit_parked", C.c_uint32),
     ]
 
 

@@ -454,3 +454,29 @@ def test_host_emit_waits_for_the_callers_stream(gpu, oracle):
             got = enc.encode_device(dl.data_ptr(), dr.data_ptr(), left, right, frames, side.cuda_stream)
         assert got == want
         del junk
+
+
+@pytest.mark.parametrize("mode", ["fused", "k_emit_only", "every_fifth_left_to_k_emit", "packer_gives_up"])
+def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
+    """The emit fused into the analysis kernel + the streaming packer beside it (default), k_offsets + k_emit alone,
+    and the two repair paths: a test hook leaves every fifth channel block to k_emit, another one fills the staging
+    slots but never announces them, so that the packer gives up and k_pack moves everything.  Same bytes every time."""
+    if mode == "k_emit_only":
+        monkeypatch.setenv("LACX_FUSED_EMIT", "0")
+    if mode == "every_fifth_left_to_k_emit":
+        monkeypatch.setenv("LACX_DEBUG_SKIP", "1024")
+    if mode == "packer_gives_up":
+        monkeypatch.setenv("LACX_DEBUG_SKIP", "8192")
+    cases = [(16384 * 40 + 321, 2, 16, 48000, 2, "mixed"), (16384 * 9 + 4000, 2, 24, 96000, 2, "mixed"),
+             (16384 * 7 + 5, 1, 16, 44100, 0, "music"), (16384 * 6, 2, 16, 48000, 1, "music"),
+             (16384 * 5 + 77, 2, 24, 48000, 0, "noise"), (16384 * 400 + 9, 2, 16, 48000, 2, "music")]
+    for frames, ch, bd, sr, sm, kind in cases:
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=71, kind=kind)
+        enc = gpu.lacx.Encoder(12, sm, sr, bd, device=0)
+        want = oracle.encode(left, right, sr, bd, sm, threads=8)
+        for _ in range(2):
+            assert enc.encode(left, right) == want, (mode, frames, ch, bd)
+        if mode == "fused":
+            t = enc.timing()
+            small_last = ch == 2 and sm == 2 and (frames % 16384) and (frames % 16384) <= 4096
+            assert t.emit_direct == (-(-frames // 16384) - (1 if small_last else 0)) * ch
