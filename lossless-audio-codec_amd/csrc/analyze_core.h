@@ -233,6 +233,8 @@ struct Smem {
     uint64_t best_bits, best_rice, best_zr, best_bin, best_static;
     uint32_t best_k0, best_sk, best_hasrun;
     int32_t best_cand;
+    int32_t next_cand;  // candidate chosen for the next exact evaluation (-1: none left)
+    uint64_t cand_key[11];  // per candidate: pruning bound * 16 + index (all ones: not available)
     uint32_t cur_k0;
     LpcSet lpc;
     // the finished plan (thread 0 writes it here, then it is copied out cooperatively) and, for the emit fused into the
@@ -257,7 +259,8 @@ struct Thread {
     unsigned long long crice, cbin, czr;  // chunk partial costs
     uint32_t chasrun;
     uint32_t lb_g;    // sum over the chunk of bit_width(u)+1 (per-sample floor of any Rice code)
-    uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16
+    uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16   (host form of the bound partials)
+    uint32_t lb_wz, lb_wf;  // device form: the wave's counts of u == 0 (incl. positions beyond the slot) and u == 4
     uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
 };
 
@@ -527,6 +530,27 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
     // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours.
     // Positions beyond the slot hold u = 0: they are summed like the others (no per-sample predicate) and taken
     // out afterwards: each adds 32 to the leading-zero sum and 1 to the zero count.
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Device form: the zero and four counts are only needed per block, so they are taken per wave from ballots -- one
+    // compare per sample, the population counts and their sum run on the scalar unit -- and clz(u) = clz(u | 1) + [u == 0]
+    // needs no special case for zero.  th.lb_g then lacks the wave's zero count, which the driver subtracts once per
+    // wave (lb_wz); lb_wz / lb_wf are wave-uniform and count the positions beyond the slot as zeros.
+    {
+        uint32_t c1sum = 0, wz = 0, wf = 0;
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) {
+            c1sum += (uint32_t)__builtin_clz(u[i] | 1u);
+            wz += (uint32_t)__popcll(__ballot(u[i] == 0u));
+            wf += (uint32_t)__popcll(__ballot(u[i] == 4u));
+        }
+        const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
+        th.lb_g = 33u * (uint32_t)th.cnt + 32u * beyond - c1sum;
+        th.lb_wz = wz;
+        th.lb_wf = wf;
+        th.lb_aux = 0;
+        return;
+    }
+#endif
     uint32_t clzsum = 0, nzero = 0, nfour = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
@@ -965,6 +989,17 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
             ak[q] = sh.xp.part.seginfo[sidx[q]].ak;
         }
     }
+    // Orders whose partition containing this chunk starts at the same sample as the next lower order's see the same
+    // prefix, the same sample counts and the same initial k, hence the same Rice and bin costs sample for sample (the
+    // zero-run cost also depends on where the partition ends, so this holds for the ZR = false instance only).
+    // Partitions of the low orders span whole waves: when every lane agrees, the order is skipped and takes its
+    // sums from the lower one afterwards (about 1.5 of 8 orders on a 16384-sample block).
+    uint32_t dup = 0;  // bit q: order q + 1 repeats order q (wave-uniform)
+    if (!ZR) {
+#pragma unroll
+        for (int q = 1; q < G::MAXP; ++q)
+            if (q < max_p && wave_all(s[q] == s[q - 1] && ak[q] == ak[q - 1])) dup |= 1u << q;
+    }
     int32_t fg = (int32_t)a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk (not yet clipped to a partition)
     uint32_t P = Pa;
     uint32_t u = sh.u[t];
@@ -982,7 +1017,7 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         const bool is_small = u <= 4u;
 #pragma unroll
         for (int q = 0; q < G::MAXP; ++q) {
-            if (q < max_p) {
+            if (q < max_p && !((dup >> q) & 1u)) {
                 const uint32_t cbefore = j - s[q];                       // samples of the partition before j
                 uint32_t kin = kmean32(P - Pseg[q], FIRST ? (cbefore ? cbefore : 1u) : cbefore);
                 if (FIRST) kin = (cbefore == 0) ? ak[q] : kin;
@@ -1011,6 +1046,13 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     };
     sample(0, std::true_type{});
     for (int i = 1; i < th.cnt; ++i) sample(i, std::false_type{});
+#pragma unroll
+    for (int q = 1; q < G::MAXP; ++q) {
+        if ((dup >> q) & 1u) {  // ascending: a run of repeated orders cascades
+            rice[q] = rice[q - 1];
+            bin[q] = bin[q - 1];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < G::MAXP; ++q) {
         if (q < max_p) flush(sidx[q], rice[q], bin[q], zr[q], (hasrun >> q) & 1u);

@@ -99,6 +99,23 @@ __device__ __forceinline__ uint32_t wave_scan_or_u32(uint32_t v) {
     v |= dpp_mov<kDppRowBcast31, 0xC>(0u, v);
     return v;
 }
+// inclusive prefix minimum of 64-bit keys over the 64 lanes (identity: all ones)
+__device__ __forceinline__ uint64_t wave_scan_min_u64(uint64_t v) {
+    auto step = [](uint64_t a, uint32_t lo, uint32_t hi) {
+        const uint64_t b = ((uint64_t)hi << 32) | lo;
+        return b < a ? b : a;
+    };
+#define LACX_MIN_STEP(CTRL, MASK) \
+    v = step(v, dpp_mov<CTRL, MASK>(0xFFFFFFFFu, (uint32_t)v), dpp_mov<CTRL, MASK>(0xFFFFFFFFu, (uint32_t)(v >> 32)))
+    LACX_MIN_STEP(kDppRowShr1, 0xF);
+    LACX_MIN_STEP(kDppRowShr2, 0xF);
+    LACX_MIN_STEP(kDppRowShr4, 0xF);
+    LACX_MIN_STEP(kDppRowShr8, 0xF);
+    LACX_MIN_STEP(kDppRowBcast15, 0xA);
+    LACX_MIN_STEP(kDppRowBcast31, 0xC);
+#undef LACX_MIN_STEP
+    return v;
+}
 // value of lane 63 in every lane (a scalar register)
 __device__ __forceinline__ uint32_t wave_last_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ uint64_t wave_last_u64(uint64_t v) {
@@ -132,15 +149,21 @@ __device__ __forceinline__ void scan_pz_part1(M& sh, int tid, ScanRegs<G>& r) {
     }
 }
 
+// Returns the block total of the summed values.
 template <class G, class M>
-__device__ __forceinline__ void scan_pz_part2(M& sh, int tid, const ScanRegs<G>& r) {
+__device__ __forceinline__ uint64_t scan_pz_part2(M& sh, int tid, const ScanRegs<G>& r) {
     const int lane = tid & 63, wave = tid >> 6;
-    uint64_t base = 0;
+    uint64_t base = 0, total = 0;
     int32_t zbase = -1;
-    for (int w = 0; w < wave; ++w) {
-        base += sh.wtotP[w];
+#pragma unroll
+    for (int w = 0; w < G::T / 64; ++w) {
+        const uint64_t pw = sh.wtotP[w];
         const int32_t z = sh.wtotZ[w];
-        zbase = z > zbase ? z : zbase;
+        total += pw;
+        if (w < wave) {
+            base += pw;
+            zbase = z > zbase ? z : zbase;
+        }
     }
     int32_t zprev = __shfl_up(r.zinc, 1, 64);
     if (lane == 0) zprev = -1;
@@ -150,6 +173,7 @@ __device__ __forceinline__ void scan_pz_part2(M& sh, int tid, const ScanRegs<G>&
         sh.tabP[G::T] = base + r.inc;
         sh.tabNZ[G::T] = r.zinc > zbase ? r.zinc : zbase;
     }
+    return total;
 }
 
 // Per-plane population counts of the wave's bit-sliced chunk counters, via ballots.  Ballot masks and
@@ -639,7 +663,14 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
     uint8_t* base = nullptr;
     for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
         if (bit0 != 0) lds_barrier();  // every thread has copied its part of the previous tile out of LDS
-        for (int i = tid; i < kEmitTileWords; i += G::T) sh.xp.o.obits[i] = 0;
+        {
+            // only the words this tile's bytes occupy (+ what the 16-byte copy-out may read past them)
+            const unsigned long long left_bytes = nbytes - (bit0 >> 3);
+            const int zw = left_bytes >= (unsigned long long)kEmitTileWords * 4u ? kEmitTileWords
+                                                                                 : (int)((((uint32_t)left_bytes + 15u) >> 4) * 4u + 8u);
+            const int zero_words = zw < kEmitTileWords ? zw : kEmitTileWords;
+            for (int i = tid; i < zero_words; i += G::T) sh.xp.o.obits[i] = 0;
+        }
         lds_barrier();
         BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
         if (bit0 == 0) emit_header(th, sh, &tile, orw);
@@ -780,6 +811,55 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     }
 }
 
+// Candidate scoring (ref block/encoder.cpp:337-359) by the 64 lanes of one wave; same result as score_candidate() of
+// analyze_core.h, which one thread computes in a serial chain of ~150 dependent 64-bit operations while fifteen
+// waves wait for it at the next barrier.  Static Rice cost at k: sum_j (u_j >> k) = T_k >> k with
+// T_k = sum_{b >= k} C_b << b, a suffix sum over the bit-plane counts: lane l takes plane 29 - l, one prefix scan gives
+// every T_k, lanes 14..29 hold k = 15..0; the (cost, k) minimum with ties to the lower k is a minimum of cost * 16 + k.
+template <class G>
+__device__ __forceinline__ void score_candidate_wave(Smem<G>& sh, int cand, uint32_t n, int zero_run, uint32_t k0,
+                                                     const uint32_t* planeTot, const unsigned long long* acc, int lane) {
+    const int b = 29 - lane;
+    const uint64_t w = (lane < 30) ? ((uint64_t)planeTot[b] << b) : 0ull;
+    const uint64_t tk = wave_scan_add_u64(w);  // lane l: T_(29-l)
+    uint64_t key = ~0ull;
+    if (lane >= 14 && lane < 30) key = (((tk >> b) + (uint64_t)n * (uint64_t)(1 + b)) << 4) | (uint64_t)b;  // cost < 2^45
+    const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
+    if (lane == 0) {
+        const uint64_t sbits = best_key >> 4;
+        const uint32_t sk = (uint32_t)(best_key & 15u);
+        const uint64_t rice = acc[0], bin = acc[1];
+        const uint32_t hasrun = acc[3] != 0;
+        const uint64_t zr = (zero_run && hasrun) ? acc[2] : rice;
+        const uint64_t a = rice < sbits ? rice : sbits;
+        const uint64_t c = zr < bin ? zr : bin;
+        const uint64_t best = a < c ? a : c;
+        if (sh.best_cand < 0 || best < sh.best_bits || (best == sh.best_bits && cand < sh.best_cand)) {
+            sh.best_cand = cand;
+            sh.best_bits = best;
+            sh.best_rice = rice;
+            sh.best_zr = zr;
+            sh.best_bin = bin;
+            sh.best_static = sbits;
+            sh.best_k0 = k0;
+            sh.best_sk = sk;
+            sh.best_hasrun = hasrun;
+        }
+    }
+}
+
+// estimate_initial_k (ref block/encoder.cpp:121-158) from the plane counts of the first min(256, n) samples, by the 64
+// lanes of one wave (same suffix-sum formulation as score_candidate_wave; k = 0..12, ties to the lower k).
+__device__ __forceinline__ uint32_t initial_k_wave(const uint32_t* planes256, uint32_t n, int lane) {
+    const int b = 29 - lane;
+    const uint64_t w = (lane < 30) ? ((uint64_t)planes256[b] << b) : 0ull;
+    const uint64_t tk = wave_scan_add_u64(w);  // lane l: T_(29-l)
+    const uint32_t m = n < 256u ? n : 256u;
+    uint64_t key = ~0ull;
+    if (lane >= 17 && lane < 30) key = (((tk >> b) + (uint64_t)m * (uint64_t)(1 + b)) << 4) | (uint64_t)b;
+    return (uint32_t)(wave_last_u64(wave_scan_min_u64(key)) & 15u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_analyze
 // ---------------------------------------------------------------------------------------------
@@ -814,63 +894,95 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     __syncthreads();
     STAMP(0);
 
-    int pending = -1;        // candidate whose totals thread 0 still has to score
-    uint32_t pending_k0 = 0;
-    int parity = 0;
-    for (int ci = 0; ci <= 10; ++ci) {
-        const int cand = candidate_at(ci);
+    // ---- pass 1: the pruning bound of every candidate ------------------------------------------------------------
+    // Residual in registers -> bound partials -> block sums in sh.lbacc[cand]; nothing is stored and no barrier separates
+    // the candidates (ref block/encoder.cpp:362-407 walks them one by one).
+    for (int cand = 0; cand <= 10; ++cand) {
         if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
+        if (cand >= 6 && (prm.debug_skip & 16u)) continue;
+        if (cand >= 1 && (prm.debug_skip & 64u)) continue;
         // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
         // addresses and masks derived from it out of this loop and, at the 128-VGPR budget, spills them to scratch.
         asm volatile("" : "+v"(th.a));
+        uint32_t ures[G::CH];
+        phase_r_residual(th, sh, cand, ures);
+        // block sums for the pruning bound (device form of the partials: see phase_r_residual)
+        const uint32_t g = wave_sum_u32(th.lb_g);
+        if ((tid & 63) == 0) {
+            const int32_t left = (int32_t)n - (int32_t)((tid >> 6) * 64 * G::CH);  // samples of the slot from this wave's first one on
+            const uint32_t valid = left <= 0 ? 0u : (left >= 64 * G::CH ? (uint32_t)(64 * G::CH) : (uint32_t)left);
+            const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
+            atomicAdd(&sh.lbacc[cand][0], g - th.lb_wz);
+            atomicAdd(&sh.lbacc[cand][1], (th.lb_wz - beyond) + (th.lb_wf << 16));
+        }
+    }
+    STAMP(2);
+    __syncthreads();
+    if (tid <= 10) {
+        // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
+        const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || (prm.debug_skip & 16u))) ||
+                             (tid >= 1 && (prm.debug_skip & 64u)));
+        sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], n, prm.zero_run) << 4) | (uint64_t)tid)
+                                 : ~0ull;
+    }
+    STAMP(5);
 
-        if (cand >= 6 && (prm.debug_skip & 16u)) continue;
-        if (cand >= 1 && (prm.debug_skip & 64u)) continue;
+    // ---- pass 2: exact costs, most promising candidate first ----------------------------------------------------------
+    // The reference keeps the first candidate with the strictly smallest cost = the minimum of (cost, index).  Candidates
+    // are evaluated in ascending (bound, index) order; one that cannot beat the best (cost, index) so far ends the search,
+    // because every remaining one has a bound at least as large (and, at an equal bound, a larger index).  A dismissed
+    // candidate costs nothing here: no residual, no barrier.
+    int pending = -1;        // candidate whose totals still have to be scored
+    uint32_t pending_k0 = 0;
+    uint32_t tried = 0;      // candidates already evaluated (uniform)
+    int parity = 0;
+    for (;;) {
+        if (tid < 64) {  // wave 0
+            if (pending >= 0) {
+                // previous candidate's totals sit in the other buffers: score it, then clear them
+                score_candidate_wave(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1], tid);
+                if (tid < 32) sh.planeTot[parity ^ 1][tid] = sh.planeTot256[parity ^ 1][tid] = 0;
+                if (tid < 4) sh.acc[parity ^ 1][tid] = 0;
+            }
+            // next: the untried candidate with the smallest (bound, index), unless it cannot win any more
+            const uint64_t key = (tid <= 10 && !((tried >> tid) & 1u)) ? sh.cand_key[tid] : ~0ull;
+            const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
+            if (tid == 0) {
+                sh.has4[parity] = 0;
+                int next = best_key == ~0ull ? -1 : (int)(best_key & 15u);
+                if (next >= 0 && !(prm.debug_skip & 128u) && candidate_pruned(best_key >> 4, next, sh.best_bits, sh.best_cand)) next = -1;
+                sh.next_cand = next;
+            }
+        }
+        STAMP(1);
+        __syncthreads();  // Bsel: the previous candidate is scored, the next one chosen
+        STAMP(4);
+        const int cand = sh.next_cand;
+        if (cand < 0) break;  // uniform
+        tried |= 1u << cand;
+        asm volatile("" : "+v"(th.a));  // (see pass 1)
         uint32_t* pt = sh.planeTot[parity];
         uint32_t* pt256 = sh.planeTot256[parity];
         unsigned long long* acc = sh.acc[parity];
-        if (tid == 0 && pending >= 0) {
-            // previous candidate's totals sit in the other buffers: score it, then clear them
-            score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
-            for (int b = 0; b < 32; ++b) sh.planeTot[parity ^ 1][b] = sh.planeTot256[parity ^ 1][b] = 0;
-            for (int b = 0; b < 4; ++b) sh.acc[parity ^ 1][b] = 0;
-            sh.has4[parity ^ 1] = 0;
-            pending = -1;
-        }
-        STAMP(1);
-        uint32_t ures[G::CH];
-        phase_r_residual(th, sh, cand, ures);
-        STAMP(2);
         {
-            // block sums for the pruning bound
-            const uint32_t g = wave_sum_u32(th.lb_g), a = wave_sum_u32(th.lb_aux);
-            if ((tid & 63) == 0) {
-                atomicAdd(&sh.lbacc[cand][0], g);
-                atomicAdd(&sh.lbacc[cand][1], a);
-            }
+            uint32_t ures[G::CH];
+            phase_r_residual(th, sh, cand, ures);
+            phase_r_store(th, sh, ures);
         }
-        STAMP(4);
-        __syncthreads();  // B1
-        STAMP(5);
-        // Exact pruning: the previous candidates are scored (thread 0 did it before this barrier), so
-        // sh.best_bits is final for them; a candidate that cannot beat it stops here -- its residual never left
-        // the registers, no plane counts, no scans, no adaptive passes (and nothing to clear).
-        if (!(prm.debug_skip & 128u) &&
-            candidate_pruned(candidate_lower_bound(sh.lbacc[cand][0], sh.lbacc[cand][1], n, prm.zero_run), cand,
-                             sh.best_bits, sh.best_cand))
-            continue;
-        phase_r_store(th, sh, ures);
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
         STAMP(3);
         __syncthreads();  // B1b: the wave totals of the scan
-        scan_pz_part2(sh, tid, sr);
+        const uint64_t total_u = scan_pz_part2(sh, tid, sr);
         if (!(prm.debug_skip & 1u)) plane_totals_wave(th, pt, pt256, tid);
+        // the first 256 samples all belong to wave 0: its own plane totals are complete once its atomics are (same wave,
+        // program order), so it can derive the initial k at once; every other thread reads it after B3
+        if (tid < 64) {
+            const uint32_t k0w = initial_k_wave(pt256, n, tid);
+            if (tid == 0) sh.cur_k0 = k0w;
+        }
         STAMP(6);
-        __syncthreads();  // B2
-        STAMP(7);
-        if (tid == (G::T > 64 ? 64 : 0)) sh.cur_k0 = initial_k_from_planes(pt256, n);  // read after B3
-        const bool narrow = sh.tabP[G::T] < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
+        const bool narrow = total_u < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
         if (prm.debug_skip & 2u) {
             sh.tabF[tid] = 0;
             th.has4 = 1u;
@@ -881,7 +993,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         }
         if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B3
         STAMP(8);
-        __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own)
+        __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own), prefixes in tabP
         STAMP(10);
         const uint32_t k0 = sh.cur_k0;
         if (prm.debug_skip & 4u) {
@@ -917,8 +1029,6 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         pending_k0 = k0;
         parity ^= 1;
     }
-    if (tid == 0 && pending >= 0) score_candidate(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1]);
-    __syncthreads();
 
     STAMP(15);
     // ---- partition search on the winning residual -------------------------------------------
