@@ -188,6 +188,10 @@ typedef struct lacx_wav_info {
 } lacx_wav_info;
 int lacx_wav_parse(const uint8_t* wav, uint64_t size, lacx_wav_info* out);
 int lacx_encode_wav(lacx_encoder* enc, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size);
+/* Zero-copy variant: *out points at the complete .lac inside the encoder's pinned result buffer (the device wrote the
+ * payload there, header and block table are filled in in front of it); valid until the next call on the same encoder.
+ * The upload is pipelined: the data chunk goes to the device in four pieces, each in front of its kernels. */
+int lacx_encode_wav_view(lacx_encoder* enc, const uint8_t* wav, uint64_t size, const uint8_t** out, uint64_t* out_size);
 
 /* Host-only: header + block table + payload concat of shards given in stream order. */
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,

@@ -80,8 +80,10 @@ struct lacx_encoder {
     unsigned long long slots_cap = 0;
     uint8_t* d_raw = nullptr;  // WAV data chunk as read from the file (lacx_encode_wav)
     uint64_t d_raw_cap = 0;
-    uint8_t* h_payload = nullptr;  // pinned
+    uint8_t* h_payload = nullptr;  // pinned: start of the payload inside h_payload_base
     uint64_t h_payload_cap = 0;
+    uint8_t* h_payload_base = nullptr;  // the allocation: h_prefix bytes in front of the payload take the container's
+    uint64_t h_prefix = 0;              // header + block table, so that a whole .lac can be handed out without a copy
     uint32_t* h_table = nullptr;   // pinned, [blocks][2]
     unsigned long long* h_totals = nullptr;  // pinned, per chunk payload bytes
     uint32_t* h_err = nullptr;     // pinned, per chunk
@@ -335,13 +337,14 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
 // Host emit wants many chunks (emit of chunk i overlaps the analysis of chunk i+1); with the emit on the
 // device the only host work is a copy, and two chunks (payload copy of one under the kernels of the other)
 // measured best.
-std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused = false) {
+std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused = false, bool upload = false) {
     uint32_t nchunks = nb / kMinChunkBlocks;
     // device emit without the fused path: 3 chunks up to an hour of stereo 48 kHz per call, 4 and 6 beyond (measured on a
     // 2 h shard).  With the fused emit + streaming packer nothing is left to overlap by chunking -- the payload leaves
     // while the analysis runs, and ingest / probes keep every CU busy by themselves -- and one launch set measured best
     // from 10 min to 2 h of audio (a chunked run only adds kernel boundaries).
-    const uint32_t dev_chunks = fused ? 1u : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
+    // With the input still in host memory the chunks pipeline the upload: 4 chunks (one quarter of the H2D copy exposed).
+    const uint32_t dev_chunks = fused ? (upload ? 4u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
     nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
@@ -635,9 +638,18 @@ uint64_t pinned_reservation(const lacx_encoder* e, uint64_t frames, int channels
     return frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
 }
 
+// Host-resident input of an encode whose upload is pipelined with the analysis: chunk c's PCM is copied to the device
+// on chunk c's stream right in front of its kernels, so the upload of chunk c+1 overlaps the analysis of chunk c
+// (ref src/main.cpp:658-675 reads the whole file first, then encodes).
+struct HostSrc {
+    const uint8_t* p0 = nullptr;  // planar: left; interleaved: the WAV data chunk
+    const uint8_t* p1 = nullptr;  // planar: right (null for mono)
+    uint64_t frame_bytes = 0;     // bytes per frame in p0 (and p1)
+};
+
 // Part 1: enqueue everything (no host synchronisation).
 int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
-                        hipStream_t user_stream, int layout = 0, int layout_channels = 0) {
+                        hipStream_t user_stream, int layout = 0, int layout_channels = 0, const HostSrc* hs = nullptr) {
     if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
     const int channels = layout ? layout_channels : (d_right ? 2 : 1);
     const uint32_t nb = blocks_for(frames);
@@ -647,7 +659,7 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     // k_emit runs after the analysis in any case and picks up whatever the fused path did not write).
     const char* fenv = std::getenv("LACX_FUSED_EMIT");
     const bool fused = !(fenv && *fenv == '0');
-    e->pend.chunks = plan_chunks(nb, true, fused);
+    e->pend.chunks = plan_chunks(nb, true, fused, hs != nullptr);
     const std::vector<Chunk>& chunks = e->pend.chunks;
     // Destination of k_emit: by default the pinned host buffer itself (the kernel's 16-byte stores cross PCIe
     // while later blocks are still being analysed, so no separate D2H pass is left at the end); with
@@ -667,12 +679,15 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         }
     }
     const uint64_t host_cap = pinned_reservation(e, frames, channels, nb);
-    if (host_cap > e->h_payload_cap || std::getenv("LACX_PINNED_CAP_BYTES")) {
-        if (e->h_payload) (void)hipHostFree(e->h_payload);
-        e->h_payload = nullptr;
-        e->h_payload_cap = 0;
-        HIP_TRY(e, hipHostMalloc((void**)&e->h_payload, host_cap, 0), "hipHostMalloc(payload)");
+    const uint64_t prefix = (14ull + 8ull * nb + 4095ull) & ~4095ull;  // room for the container header + block table
+    if (host_cap > e->h_payload_cap || prefix > e->h_prefix || std::getenv("LACX_PINNED_CAP_BYTES")) {
+        if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
+        e->h_payload = e->h_payload_base = nullptr;
+        e->h_payload_cap = e->h_prefix = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_payload_base, prefix + host_cap, 0), "hipHostMalloc(payload)");
+        e->h_payload = e->h_payload_base + prefix;
         e->h_payload_cap = host_cap;
+        e->h_prefix = prefix;
     }
     if (nb > e->h_table_blocks) {
         if (e->h_table) (void)hipHostFree(e->h_table);
@@ -738,6 +753,18 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
             fa.size_rec = e->ws.size_rec;
             fa.ready_rec = e->ws.ready_rec;
             fa.fuse_items = fuse_items;
+        }
+        if (hs) {  // this chunk's PCM: host -> device, on the chunk's stream, right in front of its kernels
+            const auto th0 = clk::now();
+            const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
+            const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
+            const uint64_t o = f0 * hs->frame_bytes, nbytes = (f1 - f0) * hs->frame_bytes;
+            HIP_TRY(e, hipMemcpyAsync(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_left)) + o, hs->p0 + o, nbytes,
+                                      hipMemcpyHostToDevice, s), "H2D pcm");
+            if (hs->p1)
+                HIP_TRY(e, hipMemcpyAsync(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_right)) + o, hs->p1 + o, nbytes,
+                                          hipMemcpyHostToDevice, s), "H2D pcm");
+            e->timing.h2d_ms += ms_since(th0);
         }
         // Fused emit: the packer walks the stream indices in order, so the whole-block kernels of the chunks run in that
         // order too (chunk c's waits for chunk c-1's: ev[c-1][3] is recorded behind it); what comes before them --
@@ -807,12 +834,15 @@ int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size) {
     const std::vector<Chunk>& chunks = e->pend.chunks;
     HIP_TRY(e, hipDeviceSynchronize(), "synchronize");
     const uint64_t total = e->h_totals[chunks.size() - 1];  // cumulative byte count after the last chunk
-    if (e->h_payload) (void)hipHostFree(e->h_payload);
-    e->h_payload = nullptr;
-    e->h_payload_cap = 0;
+    const uint64_t prefix = e->h_prefix;
+    if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
+    e->h_payload = e->h_payload_base = nullptr;
+    e->h_payload_cap = e->h_prefix = 0;
     const uint64_t cap = total + 4096u;
-    HIP_TRY(e, hipHostMalloc((void**)&e->h_payload, cap, 0), "hipHostMalloc(payload regrow)");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_payload_base, prefix + cap, 0), "hipHostMalloc(payload regrow)");
+    e->h_payload = e->h_payload_base + prefix;
     e->h_payload_cap = cap;
+    e->h_prefix = prefix;
     uint8_t* dst = nullptr;
     HIP_TRY(e, hipHostGetDevicePointer((void**)&dst, e->h_payload, 0), "hipHostGetDevicePointer");
     hipStream_t s = e->stream[0];
@@ -927,8 +957,9 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
 }
 
 int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
-                            hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0) {
-    const int rc = encode_device_begin(e, d_left, d_right, frames, user_stream, layout, layout_channels);
+                            hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0,
+                            const HostSrc* hs = nullptr) {
+    const int rc = encode_device_begin(e, d_left, d_right, frames, user_stream, layout, layout_channels, hs);
     if (rc) return rc;
     return encode_device_end(e, payload_size);
 }
@@ -1026,7 +1057,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->d_payload) (void)hipFree(e->d_payload);
         if (e->slots) (void)hipFree(e->slots);
         if (e->d_raw) (void)hipFree(e->d_raw);
-        if (e->h_payload) (void)hipHostFree(e->h_payload);
+        if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
         if (e->h_err) (void)hipHostFree(e->h_err);
@@ -1180,6 +1211,41 @@ int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint
     e->timing = lacx_timing{};
     int rc = prepare(e, left, frames);
     if (rc) return rc;
+    if (!(e->cfg.flags & LACX_FLAG_HOST_EMIT)) {
+        // device emit: the upload is pipelined with the analysis (chunk c+1's PCM crosses PCIe under chunk c's kernels)
+        rc = ensure_pcm(e, frames, right != nullptr);
+        if (rc) return rc;
+        HostSrc hs;
+        hs.p0 = reinterpret_cast<const uint8_t*>(left);
+        hs.p1 = reinterpret_cast<const uint8_t*>(right);
+        hs.frame_bytes = sizeof(int32_t);
+        uint64_t pay = 0;
+        rc = encode_pipelined_device(e, e->d_left, right ? e->d_right : nullptr, frames, nullptr, &pay, 0, 0, &hs);
+        if (rc == LACX_OK) {
+            const uint32_t nb = blocks_for(frames);
+            const uint64_t head = 10 + 4 + 8ull * nb;
+            uint8_t* lac = e->h_payload - head;  // h_prefix >= head bytes are reserved in front of the payload
+            write_frame_header(stream_params(e->cfg, right ? 2 : 1), lac);
+            put32(lac + 10, nb);
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (e->h_table[2 * b + 1] == 0) return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+                put32(lac + 14 + 8ull * b, e->h_table[2 * b]);
+                put32(lac + 18 + 8ull * b, e->h_table[2 * b + 1]);
+            }
+            uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + pay));
+            if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
+            big_copy(buf, lac, head + pay);
+            *out = buf;
+            *out_size = head + pay;
+            e->timing.total_ms = ms_since(t0);
+            return LACX_OK;
+        }
+        if (rc != -1) return rc;
+        // -1 (only with LACX_EMIT_STAGED): fall through to the host-emit pipeline; the PCM is on the device already
+        rc = lacx_encode_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr, out, out_size);
+        e->timing.total_ms = ms_since(t0);
+        return rc;
+    }
     rc = upload(e, left, right, frames);
     if (rc) return rc;
     rc = lacx_encode_device(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr, out, out_size);
@@ -1358,8 +1424,9 @@ int lacx_wav_parse(const uint8_t* wav, uint64_t size, lacx_wav_info* out) {
     return LACX_OK;
 }
 
-int lacx_encode_wav(lacx_encoder* e, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size) {
-    if (!e || !out || !out_size) return LACX_E_INVALID;
+// WAV image in host memory -> complete .lac in the encoder's pinned result buffer (header and block table are written
+// in front of the payload, which the device put there itself): no copy of the result at all.
+static int encode_wav_in_place(lacx_encoder* e, const uint8_t* wav, uint64_t size, const uint8_t** out, uint64_t* out_size) {
     const auto t0 = clk::now();
     e->timing = lacx_timing{};
     WavInfo w;
@@ -1376,21 +1443,50 @@ int lacx_encode_wav(lacx_encoder* e, const uint8_t* wav, uint64_t size, uint8_t*
         HIP_TRY(e, hipMalloc((void**)&e->d_raw, w.data_bytes + 16u), "hipMalloc(wav data)");
         e->d_raw_cap = w.data_bytes + 16u;
     }
-    // the data chunk as it is in the file: interleaved little-endian int16 / packed int24 (coalesced ingest)
-    HIP_TRY(e, hipMemcpy(e->d_raw, wav + w.data_offset, w.data_bytes, hipMemcpyHostToDevice), "H2D wav data");
-    e->timing.h2d_ms = ms_since(t0);
+    // The data chunk as it is in the file: interleaved little-endian int16 / packed int24 (coalesced ingest), uploaded
+    // chunk by chunk in front of each pipeline chunk's kernels (the upload of chunk c+1 overlaps the analysis of chunk c).
+    HostSrc hs;
+    hs.p0 = wav + w.data_offset;
+    hs.frame_bytes = (uint64_t)w.channels * (w.bit_depth / 8u);
     const int layout = w.bit_depth == 16 ? (int)LACX_PCM_INTERLEAVED_I16 : (int)LACX_PCM_INTERLEAVED_I24;
     uint64_t pay = 0;
     rc = encode_pipelined_device(e, reinterpret_cast<const int32_t*>(e->d_raw), nullptr, w.frames, nullptr, &pay, layout,
-                                 (int)w.channels);
+                                 (int)w.channels, &hs);
     if (rc == -1) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
     if (rc) return rc;
-    const uint8_t* payloads[1] = {e->h_payload};
-    const uint64_t sizes[1] = {pay};
-    const uint32_t* tables[1] = {e->h_table};
-    const uint32_t nbs[1] = {blocks_for(w.frames)};
-    rc = lacx_assemble(&e->cfg, (int)w.channels, 1, payloads, sizes, tables, nbs, out, out_size);
-    if (rc) return fail(e, rc, "container assembly failed");
+    const uint32_t nb = blocks_for(w.frames);
+    const uint64_t head = 10 + 4 + 8ull * nb;
+    uint8_t* lac = e->h_payload - head;  // h_prefix >= head bytes are reserved in front of the payload
+    write_frame_header(stream_params(e->cfg, (int)w.channels), lac);
+    put32(lac + 10, nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (e->h_table[2 * b + 1] == 0) return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+        put32(lac + 14 + 8ull * b, e->h_table[2 * b]);
+        put32(lac + 18 + 8ull * b, e->h_table[2 * b + 1]);
+    }
+    *out = lac;
+    *out_size = head + pay;
+    e->timing.total_ms = ms_since(t0);
+    return LACX_OK;
+}
+
+int lacx_encode_wav_view(lacx_encoder* e, const uint8_t* wav, uint64_t size, const uint8_t** out, uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    return encode_wav_in_place(e, wav, size, out, out_size);
+}
+
+int lacx_encode_wav(lacx_encoder* e, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size) {
+    if (!e || !out || !out_size) return LACX_E_INVALID;
+    const auto t0 = clk::now();
+    const uint8_t* view = nullptr;
+    uint64_t n = 0;
+    const int rc = encode_wav_in_place(e, wav, size, &view, &n);
+    if (rc) return rc;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(n ? n : 1));
+    if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
+    big_copy(buf, view, n);
+    *out = buf;
+    *out_size = n;
     e->timing.total_ms = ms_since(t0);
     return LACX_OK;
 }

@@ -88,7 +88,7 @@ EXPORTS = (
     "lacx_encode", "lacx_encode_device", "lacx_analyze", "lacx_analyze_device", "lacx_emit_from_plans",
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
-    "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers",
+    "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers", "lacx_encode_wav_view",
 )
 
 
@@ -351,6 +351,19 @@ class Encoder:
             return C.string_at(out, size.value)
         finally:
             lib().lacx_free(out)
+
+    def encode_wav_view(self, wav) -> "PayloadView":
+        """Zero-copy form of encode_wav: a view of the complete .lac in the encoder's pinned result buffer (valid until
+        the encoder's next call); `wav` is any buffer (bytes, numpy uint8 array, mmap)."""
+        out = C.POINTER(C.c_uint8)()
+        size = C.c_uint64()
+        h = self._handle()
+        view = np.frombuffer(wav, dtype=np.uint8)
+        rc = lib().lacx_encode_wav_view(h, view.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint64(view.size), C.byref(out),
+                                        C.byref(size))
+        if rc != OK:
+            _raise(h, rc)
+        return PayloadView(out, size.value)
 
     def encode_shard_pcm_device_view(self, data_ptr: int, layout: int, channels: int, frames: int, stream: int = 0):
         """Zero-copy shard encode of device-resident PCM in its source layout (interleaved int16 / int24)."""

@@ -264,6 +264,14 @@ def test_encode_wav_matches_reference_chain(gpu, oracle):
     assert gpu.lacx.Encoder(12, 2, 48000, 16).encode_wav(wav) == oracle.encode(l16, r16, 48000, 16, 2, threads=8)
     wav = W.make_wav(l24, None, 96000, 24, between=[W.chunk(b"fact", b"12345")])
     assert gpu.lacx.Encoder(12, 0, 96000, 24).encode_wav(wav) == oracle.encode(l24, None, 96000, 24, 0, threads=8)
+    assert gpu.lacx.Encoder(12, 0, 96000, 24).encode_wav_view(wav).tobytes() == oracle.encode(l24, None, 96000, 24, 0, threads=8)
+    # pipelined upload (several chunks) + in-place container
+    lbig, rbig = gpu.synth.synth_pcm(16384 * 700 + 33, 2, 16, 48000, seed=33, kind="music")
+    wbig = W.make_wav(lbig, rbig, 48000, 16)
+    enc = gpu.lacx.Encoder(12, 2, 48000, 16)
+    want = oracle.encode(lbig, rbig, 48000, 16, 2, threads=8)
+    assert enc.encode_wav_view(wbig).tobytes() == want
+    assert enc.encode_wav(wbig) == want
     with pytest.raises(ValueError, match="differs from the encoder"):
         gpu.lacx.Encoder(12, 0, 48000, 24).encode_wav(wav)
     with pytest.raises(ValueError, match="not a supported PCM WAV"):
