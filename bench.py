@@ -287,7 +287,8 @@ def worker(args) -> int:
 
     # ---- roofline of the dominant kernel: k_analyze<16,1024> (whole-block analysis) ----------
     # algorithmic bytes per launch = samples it analyses x bit_depth/8 (each PCM byte once)
-    # + the plan records it writes (296 B per analysed channel block).
+    # + the plan records it writes (296 B per analysed channel block) + -- the bit emit being fused into this kernel --
+    # the bitstream bytes it writes once.
     # The pipeline launches the kernel once per chunk: duration and bytes are per launch (averages).
     # Two live measurements of a launch: (a) hipEvents around it on its stream -- the contract's figure, used for
     # `achieved`; with the pipeline's chunks on prioritised streams it includes the time a launch queues behind /
@@ -296,7 +297,8 @@ def worker(args) -> int:
     n_launch = mean("launches")
     kernel_s = mean("full_ms") / 1e3 / n_launch
     exec_s = mean("exec_ms") / 1e3 / n_launch
-    algo_bytes = (frames * 2 * (bit_depth // 8) + tm.full_slots * 296) / n_launch
+    fused_payload = len(main["last"][0]) if (main["last"] is not None and tm.emit_direct > 0) else 0
+    algo_bytes = (frames * 2 * (bit_depth // 8) + tm.full_slots * 296 + fused_payload) / n_launch
     achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     default_run = (workload == "cfg2" and not args.seconds and world == 1 and not args.host_emit and std_format)
     traffic = None
