@@ -208,7 +208,7 @@ int lacx_debug_lpc(lacx_encoder* enc, const int32_t* pcm, uint32_t n, int64_t* a
                    uint8_t* used);
 
 /* Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums of k_analyze<16,1024>; returns 0 in
- * production builds. out32[24] = number of waves accumulated. */
+ * production builds. out[40]; out[32] = number of waves accumulated. */
 int lacx_debug_stamps(unsigned long long* out32);
 
 /* Host-side worker threads the encoder's emit pool runs besides the calling thread (creates the pool; no device

@@ -29,15 +29,19 @@ namespace lacx {
 
 // Diagnostic phase stamps (only in builds made with -DLACX_STAMPS; the production kernel has none).
 #ifdef LACX_STAMPS
-__device__ unsigned long long g_stamp_acc[32];
+__device__ unsigned long long g_stamp_acc[40];
 #define STAMP(k)                                                        \
     do {                                                                \
         const unsigned long long _now = __builtin_amdgcn_s_memtime();   \
         stamp_acc[k] += _now - stamp_prev;                              \
         stamp_prev = _now;                                              \
     } while (0)
+#define STAMP_PARAMS , unsigned long long* stamp_acc, unsigned long long& stamp_prev
+#define STAMP_ARGS , stamp_acc, stamp_prev
 #else
 #define STAMP(k) do { } while (0)
+#define STAMP_PARAMS
+#define STAMP_ARGS
 #endif
 // ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
@@ -622,7 +626,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <class G, class M, class Resolve>
 __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint8_t* __restrict__ out,
                                           uint32_t* __restrict__ err_flag, Resolve&& resolve, const int tid,
-                                          const bool ablate_stores = false, const uint32_t slot_bytes = 0) {
+                                          const bool ablate_stores, const uint32_t slot_bytes STAMP_PARAMS) {
     (void)out;
     const bool narrow = sh.tabP[G::T] < (1ull << 31);
     const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
@@ -634,11 +638,13 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
         }
         __syncthreads();
     }
+    STAMP(25);
     auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
     auto stw = [](uint32_t* w, uint32_t v) { *w = v; };
     // walk 1: Rice parameter per sample + token bits of the chunk
     const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw, stw)
                                              : emit_walk<G, false>(th, sh, nullptr, 0, orw, stw);
+    STAMP(26);
     __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
     sh.tabP[tid] = mybits;
     {
@@ -658,6 +664,7 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
     if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
     if (nbytes != sh.payload_bytes || sh.err) return false;  // uniform: never write outside the planned byte range
     const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
+    STAMP(27);
 
     // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
     uint8_t* base = nullptr;
@@ -672,6 +679,7 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
             for (int i = tid; i < zero_words; i += G::T) sh.xp.o.obits[i] = 0;
         }
         lds_barrier();
+        STAMP(28);
         BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
         if (bit0 == 0) emit_header(th, sh, &tile, orw);
         const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
@@ -682,7 +690,9 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
                 emit_walk<G, false>(th, sh, &tile, mypos, orw, stw);
             }
         }
+        STAMP(29);
         lds_barrier();
+        STAMP(30);
         if (bit0 == 0 && !resolve(&base)) return false;  // uniform
         const unsigned long long byte0 = bit0 >> 3;
         const unsigned long long left = nbytes - byte0;
@@ -737,6 +747,7 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
             if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
         }
         // no barrier and no wait for the stores here: the workgroup may retire while they are still on their way
+        STAMP(31);
     }
     return true;
 }
@@ -775,7 +786,7 @@ __device__ __forceinline__ void rec_store(unsigned long long* p, unsigned long l
 template <class G>
 __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const AnalyzeParams& prm, const FuseArgs& fa,
                                            const long long idx, const bool flag_byte, const uint32_t flag_value,
-                                           const int tid) {
+                                           const int tid STAMP_PARAMS) {
     const uint32_t n = th.n;
     // Optimisation barrier on the thread's coordinates: without it the compiler computes the LDS addresses of the emit
     // phases at kernel entry and keeps them alive (spilled to scratch) through the whole analysis.
@@ -790,15 +801,20 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     bool done = false;
     if (!skip) {  // uniform
         emit_load_plan(sh, sh.plan, tid, G::T);
-        __syncthreads();
-        emit_first_nonzero(th, sh);
-        const int32_t nxinc = scan_nx_part1<G>(sh, tid, sh.wx);
-        __syncthreads();
-        scan_nx_part2<G>(sh, tid, nxinc, sh.wx, (int32_t)n);
-        __syncthreads();
+        // the "first non-zero sample after me" table is only read by zero-run partitions (mode 1)
+        const uint32_t nparts = sh.plan.partition_order ? (1u << sh.plan.partition_order) : 1u;
+        const bool any_zr = __syncthreads_or((uint32_t)tid < nparts && (sh.plan.part_mode_k[(uint32_t)tid < nparts ? tid : 0] >> 5) == 1u);
+        if (any_zr) {  // uniform
+            emit_first_nonzero(th, sh);
+            const int32_t nxinc = scan_nx_part1<G>(sh, tid, sh.wx);
+            __syncthreads();
+            scan_nx_part2<G>(sh, tid, nxinc, sh.wx, (int32_t)n);
+            __syncthreads();
+        }
         uint8_t* slot = fa.slots + (unsigned long long)idx * fa.slot_stride;
+        STAMP(24);
         done = emit_body<G>(sh, th, n, slot, fa.err_flag, [slot](uint8_t** o) { *o = slot; return true; }, tid,
-                            (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride);
+                            (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride STAMP_ARGS);
     }
     // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
     // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1)
@@ -873,8 +889,8 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
     const uint32_t n = n_in;
 #ifdef LACX_STAMPS
-    unsigned long long stamp_acc[24];
-    for (int k = 0; k < 24; ++k) stamp_acc[k] = 0;
+    unsigned long long stamp_acc[40];
+    for (int k = 0; k < 40; ++k) stamp_acc[k] = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
     const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1114,7 +1130,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
     STAMP(21);
     if constexpr (G::T == 1024) {
-        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid);  // uniform
+        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid STAMP_ARGS);  // uniform
     }
     STAMP(23);
 #if defined(LACX_STAMPS) && LACX_STAMPS == 1
@@ -1122,8 +1138,8 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     // sums to the same addresses the atomics themselves slowed every global load in the kernel down severalfold
     if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u) && G::T == 1024) {
         stamp_acc[22] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
-        for (int k = 0; k < 24; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
-        atomicAdd(&g_stamp_acc[24], 1ull);
+        for (int k = 0; k < 32; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
+        atomicAdd(&g_stamp_acc[32], 1ull);
     }
 #endif
 }
@@ -1138,7 +1154,8 @@ __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L,
                                                   unsigned long long* __restrict__ t_last, FuseArgs fuse) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x;
-    if (t_first && tid == 0) atomicMin(t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
+    if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
     // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
     // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
@@ -1307,7 +1324,11 @@ __device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx
     scan_pz_part2<G>(sh, tid, sr);
     scan_nx_part2<G>(sh, tid, nxinc, s_wx, (int32_t)n);
     __syncthreads();
-    emit_body<G>(sh, th, n, out, err_flag, [out, off](uint8_t** o) { *o = out + off; return true; }, tid);
+#ifdef LACX_STAMPS
+    unsigned long long stamp_acc[40];
+    unsigned long long stamp_prev = 0;
+#endif
+    emit_body<G>(sh, th, n, out, err_flag, [out, off](uint8_t** o) { *o = out + off; return true; }, tid, false, 0u STAMP_ARGS);
 }
 
 // k_emit: the bitstream of every channel block of the chunk that the fused emit has not produced (emitted[] == 0;
@@ -1501,8 +1522,8 @@ size_t analyze_smem_bytes_full() { return sizeof(Smem<GFull>); }
 
 int debug_read_stamps(unsigned long long* out32) {
 #ifdef LACX_STAMPS
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * 32) != hipSuccess) return 0;
-    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * 40) != hipSuccess) return 0;
+    unsigned long long zero[40] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof(zero));
     return 1;
 #else

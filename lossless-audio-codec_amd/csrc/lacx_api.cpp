@@ -89,7 +89,9 @@ struct lacx_encoder {
     uint32_t* h_err = nullptr;     // pinned, per chunk
     uint32_t* h_emitted = nullptr; // pinned copy of ws.emitted (statistics of the fused emit)
     uint32_t h_emitted_cap = 0;
-    unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: first-start / last-end device clock of k_analyze<16,1024>
+    unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: ~first-start / last-end device clock of k_analyze<16,1024>
+    uint8_t* zero_region = nullptr;         // one allocation for everything that is zeroed before every call
+    size_t zero_bytes = 0;
     unsigned long long* h_tspan = nullptr;  // pinned copy
     uint32_t h_table_blocks = 0;
     uint8_t* view_buf = nullptr;   // result of the host-emit fallback kept alive for the *_view API
@@ -180,7 +182,6 @@ int ensure_device(lacx_encoder* e) {
         HIP_TRY(e, hipStreamCreateWithPriority(&e->pack_stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
     }
     HIP_TRY(e, hipEventCreateWithFlags(&e->pack_done, hipEventDisableTiming), "hipEventCreate");
-    HIP_TRY(e, hipMalloc((void**)&e->d_tspan, sizeof(unsigned long long) * 2 * kMaxChunks), "hipMalloc(tspan)");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_tspan, sizeof(unsigned long long) * 2 * kMaxChunks, 0), "hipHostMalloc");
     e->device_ready = true;
     return LACX_OK;
@@ -206,10 +207,9 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.badidx) (void)hipFree(e->ws.badidx);
     if (e->ws.block_off) (void)hipFree(e->ws.block_off);
     if (e->ws.table) (void)hipFree(e->ws.table);
-    if (e->ws.err_flag) (void)hipFree(e->ws.err_flag);
-    if (e->ws.emitted) (void)hipFree(e->ws.emitted);
-    if (e->ws.packed) (void)hipFree(e->ws.packed);
-    if (e->ws.size_rec) (void)hipFree(e->ws.size_rec);
+    if (e->zero_region) (void)hipFree(e->zero_region);  // size_rec, ready_rec, tspan, emitted, packed, err_flag
+    e->zero_region = nullptr;
+    e->d_tspan = nullptr;
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -229,14 +229,28 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
                 "hipMalloc(block_off)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
-        HIP_TRY(e, hipMalloc((void**)&e->ws.err_flag, sizeof(uint32_t) * (kMaxChunks + 1)), "hipMalloc(err)");
-        // fused emit: one flag per channel block of the shard (the staging slots are sized per call, ensure_slots)
-        HIP_TRY(e, hipMalloc((void**)&e->ws.emitted, ((size_t)nblocks * 2 + 4) * sizeof(uint32_t)), "hipMalloc(emitted)");
-        HIP_TRY(e, hipMalloc((void**)&e->ws.packed, ((size_t)nblocks * 2 + 4) * sizeof(uint32_t)), "hipMalloc(packed)");
-        // size records and ready records of the fused emit, one allocation (zeroed together before every call)
-        HIP_TRY(e, hipMalloc((void**)&e->ws.size_rec, ((size_t)nblocks * 4 + 4) * sizeof(unsigned long long)),
-                "hipMalloc(hand-off records)");
-        e->ws.ready_rec = e->ws.size_rec + ((size_t)nblocks * 2 + 2);
+
+        // Everything a call needs zeroed up front lives in ONE allocation, cleared by one memset: the hand-off records
+        // and flags of the fused emit (per channel block of the shard), the error flags, the kernel time stamps.
+        {
+            const size_t items = (size_t)nblocks * 2 + 4;
+            const size_t bytes = items * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) +
+                                 sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 4);
+            e->zero_bytes = (bytes + 15) & ~(size_t)15;
+            HIP_TRY(e, hipMalloc((void**)&e->zero_region, e->zero_bytes), "hipMalloc(zeroed region)");
+            uint8_t* p = e->zero_region;
+            e->ws.size_rec = reinterpret_cast<unsigned long long*>(p);
+            p += items * sizeof(unsigned long long);
+            e->ws.ready_rec = reinterpret_cast<unsigned long long*>(p);
+            p += items * sizeof(unsigned long long);
+            e->d_tspan = reinterpret_cast<unsigned long long*>(p);
+            p += sizeof(unsigned long long) * 2 * kMaxChunks;
+            e->ws.emitted = reinterpret_cast<uint32_t*>(p);
+            p += items * sizeof(uint32_t);
+            e->ws.packed = reinterpret_cast<uint32_t*>(p);
+            p += items * sizeof(uint32_t);
+            e->ws.err_flag = reinterpret_cast<uint32_t*>(p);
+        }
         e->ws_blocks = nblocks;
     }
     if (nblocks > e->h_blocks) {
@@ -708,9 +722,7 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         emit_cap = e->h_payload_cap;
     }
     const unsigned long long* prev_end = nullptr;  // device address of the byte total of the chunks so far
-    HIP_TRY(e, hipMemsetAsync(e->ws.err_flag, 0, sizeof(uint32_t) * (kMaxChunks + 1), st[0]), "memset");
-    HIP_TRY(e, hipMemsetAsync(e->d_tspan, 0xFF, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
-    HIP_TRY(e, hipMemsetAsync(e->d_tspan + kMaxChunks, 0, sizeof(unsigned long long) * kMaxChunks, st[0]), "memset");
+    HIP_TRY(e, hipMemsetAsync(e->zero_region, 0, e->zero_bytes, st[0]), "memset");  // records, flags, time stamps
     if (fused) {
         rc = ensure_slots(e, nb, channels);
         if (rc) return rc;
@@ -724,9 +736,6 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     } else {
         e->ws.slots = nullptr;
     }
-    HIP_TRY(e, hipMemsetAsync(e->ws.emitted, 0, ((size_t)nb * 2 + 4) * sizeof(uint32_t), st[0]), "memset");
-    HIP_TRY(e, hipMemsetAsync(e->ws.packed, 0, ((size_t)nb * 2 + 4) * sizeof(uint32_t), st[0]), "memset");
-    HIP_TRY(e, hipMemsetAsync(e->ws.size_rec, 0, ((size_t)nb * 4 + 4) * sizeof(unsigned long long), st[0]), "memset");
     HIP_TRY(e, hipEventRecord(e->prologue, st[0]), "event record");
     // Stream indices that take part in the fused emit: all but those of a final block of <= 4096 frames in per-block
     // stereo mode, which may be encoded both ways and compared afterwards (ref lac/encoder.cpp:336-340).
@@ -949,7 +958,7 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     }
     e->timing.full_exec_ms = 0;
     for (size_t c = 0; c < chunks.size(); ++c) {
-        const unsigned long long a = e->h_tspan[c], b = e->h_tspan[kMaxChunks + c];
+        const unsigned long long a = ~e->h_tspan[c], b = e->h_tspan[kMaxChunks + c];  // the start stamp is kept inverted
         if (b > a) e->timing.full_exec_ms += (double)(b - a) * 1e-5;  // 100 MHz device clock -> ms
     }
     *payload_size = off;
@@ -1063,7 +1072,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->h_err) (void)hipHostFree(e->h_err);
         if (e->h_emitted) (void)hipHostFree(e->h_emitted);
         if (e->h_tspan) (void)hipHostFree(e->h_tspan);
-        if (e->d_tspan) (void)hipFree(e->d_tspan);
+
         for (auto& s : e->stream)
             if (s) (void)hipStreamDestroy(s);
     }

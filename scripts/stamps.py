@@ -15,15 +15,15 @@ inter = pkg.synth.interleave(L, R, bd)
 d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
 enc = pkg.lacx.Encoder(12, 2, 48000, bd, device=0)
 lib = pkg.lacx.lib()
-buf = (C.c_ulonglong * 32)()
+buf = (C.c_ulonglong * 40)()
 layout = pkg.lacx.PCM_INTERLEAVED_I16 if bd == 16 else pkg.lacx.PCM_INTERLEAVED_I24
 for it in range(iters):
     enc.encode_shard_pcm_device_view(d.data_ptr(), layout, 2, L.size, 0)
     lib.lacx_debug_stamps(buf)
-names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "-", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "fused emit"]
-idx = [i for i in range(24) if i != 22]
+names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "-", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish"]
+idx = [i for i in range(32) if i != 22]
 tot = sum(buf[i] for i in idx)
-waves = buf[24]
+waves = buf[32]
 t = enc.timing()
 print(f"waves {waves}, cycles/wave {tot / max(1, waves):.0f}, full_ms {t.full_ms:.3f}, realtime ticks/wave {buf[22] / max(1, waves):.0f} -> shader clock {tot / max(1, buf[22]) * 0.1:.3f} GHz, wave lifetime {buf[22] / max(1, waves) / 100:.1f} us")
 for i in idx:
