@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
     ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
+    ap.add_argument("--inflight", type=int, default=1, choices=(1, 2),
+                    help="diagnostic: 2 = step i+1 is enqueued on a second encoder before step i's result is collected")
     return ap.parse_args(argv)
 
 
@@ -200,6 +202,32 @@ def worker(args) -> int:
                 dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
             return payload, table
 
+        inflight = args.inflight if (interleaved and world == 1) else 1
+        if inflight == 2:
+            encs2 = [enc, lacx.Encoder(12, STEREO_MODE, sample_rate, bit_depth, device=device)]
+
+            def run2(nsteps):
+                last_ = None
+                for i in range(nsteps):
+                    encs2[i % 2].encode_shard_pcm_device_begin(d_pcm.data_ptr(), layout, 2, frames, stream)
+                    if i >= 1:
+                        last_ = encs2[(i - 1) % 2].encode_shard_end()
+                if nsteps:
+                    last_ = encs2[(nsteps - 1) % 2].encode_shard_end()
+                return last_
+
+            run2(args.warmup)
+            sync()
+            t0 = time.perf_counter()
+            last = run2(args.steps)
+            sync()
+            elapsed = time.perf_counter() - t0
+            tm = enc.timing()
+            rec = dict(full_ms=[tm.full_ms], analysis_ms=[tm.analysis_ms], emit_ms=[tm.emit_ms], probe_ms=[tm.probe_ms],
+                       ingest_ms=[tm.ingest_ms], launches=[max(1, tm.full_launches)], api_ms=[tm.total_ms], exec_ms=[tm.full_exec_ms])
+            return dict(tag=tag, total_frames=total_frames, total_blocks=total_blocks, b0=b0, b1=b1, frames=frames,
+                        elapsed=elapsed, last=last, rec=rec, timing=tm, left=left, right=right, keep_alive=encs2,
+                        value=total_frames * 2 * args.steps / elapsed / 1e6, ms_per_step=elapsed / args.steps * 1e3)
         for _ in range(args.warmup):
             step()
         sync()

@@ -781,8 +781,10 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         const bool chain = fused && c > 0 && !std::getenv("LACX_NO_CHAIN");
         HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
         if (c == 0 && fuse_items && !std::getenv("LACX_NO_PACKER")) {
-            // the streaming packer: beside the analysis kernels, on its own stream, from the first chunk's analysis on
-            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->prologue, 0), "stream wait");
+            // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first
+            // chunk's ingest / Levinson / probe kernels are done (ev[0][2] is recorded right in front of the whole-block
+            // kernel), so its bounded waits only ever cover the progress of the analysis itself, however long the shard.
+            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][2], 0), "stream wait");
             HIP_TRY(e, launch_stream_out(fuse_items, (channels == 2 && e->cfg.stereo_mode == 2) ? 1 : 0, e->ws, emit_dst,
                                          emit_cap, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");

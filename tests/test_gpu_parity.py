@@ -376,6 +376,28 @@ def test_cli_encode_command(gpu, oracle, tmp_path):
     bad = subprocess.run([cli, "encode", str(tmp_path / "missing.wav"), str(tmp_path / "x.lac")], capture_output=True, text=True)
     assert bad.returncode == 1 and "Failed to read WAV" in bad.stderr
     assert subprocess.run([cli, "encode", str(wav), str(wav)], capture_output=True).returncode == 1
+    # same file under another spelling / through a symlink (ref src/main.cpp:433-444), input must survive
+    link = tmp_path / "alias.wav"
+    os.symlink(wav, link)
+    before = wav.read_bytes()
+    for other in (str(tmp_path / "." / "in.wav"), str(link)):
+        res = subprocess.run([cli, "encode", str(wav), other], capture_output=True, text=True)
+        assert res.returncode == 1 and "Input and output paths must be different" in res.stderr
+    assert wav.read_bytes() == before
+    # the reference's --debug-* flags are accepted; LAC_THREADS is resolved by the tool (ref :586-591, thread_limit.hpp)
+    env = dict(os.environ, LAC_THREADS="3")
+    res = subprocess.run([cli, "encode", str(wav), str(tmp_path / "d.lac"), "--debug-threads", "--debug-lpc", "--debug-stereo-est",
+                          "--debug-zr", "--debug-partitions"], capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stderr
+    assert (tmp_path / "d.lac").read_bytes() == oracle.encode(left, right, 96000, 24, 2, threads=8)
+    base = oracle.encode(left, right, 96000, 24, 2, zero_run=False, threads=8)
+    assert f"[debug-zr] baseline_bytes={len(base)} zr_bytes={len((tmp_path / 'd.lac').read_bytes())}" in res.stdout
+    assert "Thread usage: 1 threads" in res.stdout
+    for bad_env in ("0", "x3", "-1"):
+        res = subprocess.run([cli, "encode", str(wav), str(tmp_path / "e.lac")], capture_output=True, text=True,
+                             env=dict(os.environ, LAC_THREADS=bad_env))
+        assert res.returncode == 1 and "LAC_THREADS must be a positive integer" in res.stderr
+    assert subprocess.run([cli, "encode", str(wav), str(tmp_path / "f.lac"), "--bogus"], capture_output=True).returncode == 1
 
 
 def test_two_encoders_on_two_host_threads(gpu, oracle):
