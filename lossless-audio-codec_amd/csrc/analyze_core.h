@@ -245,8 +245,7 @@ struct Smem {
     uint8_t part_mode_k[kMaxParts];
     uint32_t ptype, order, p, parts, cand, header_bits, payload_bytes;
     uint32_t err;
-    unsigned long long lb_off;  // byte offset of this channel block in the shard payload (decoupled look-back)
-    uint32_t lb_ok;
+    uint32_t plan_any_zr;  // finalize_plan: some partition of the plan uses zero-run mode
 };
 
 template <class G>
@@ -1137,12 +1136,19 @@ LACX_HD void finalize_plan(Smem<G>& sh, uint32_t n, int zero_run, int max_p, Cha
     out->partition_order = (uint8_t)best_p;
     out->total_bits = best_total;
     out->payload_bytes = (uint32_t)((16u + (ptype == 2 ? 16u * order : 0u) + best_total) >> 3);
+    uint32_t any_zr = 0;  // some partition is coded in zero-run mode (the emit then needs the run-length table)
     if (best_p == 0) {
         out->part_mode_k[0] = (uint8_t)((mode << 5) | k);
+        any_zr = mode == 1u;
     } else {
         const uint32_t parts = 1u << best_p, segbase = (2u << (best_p - 1)) - 2u;
-        for (uint32_t i = 0; i < parts; ++i) out->part_mode_k[i] = sh.xp.part.choice[segbase + i];
+        for (uint32_t i = 0; i < parts; ++i) {
+            const uint8_t c = sh.xp.part.choice[segbase + i];
+            out->part_mode_k[i] = c;
+            any_zr |= (uint32_t)((c >> 5) == 1u);
+        }
     }
+    sh.plan_any_zr = any_zr;
 }
 
 }  // namespace lacx

@@ -801,10 +801,9 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     bool done = false;
     if (!skip) {  // uniform
         emit_load_plan(sh, sh.plan, tid, G::T);
+        __syncthreads();
         // the "first non-zero sample after me" table is only read by zero-run partitions (mode 1)
-        const uint32_t nparts = sh.plan.partition_order ? (1u << sh.plan.partition_order) : 1u;
-        const bool any_zr = __syncthreads_or((uint32_t)tid < nparts && (sh.plan.part_mode_k[(uint32_t)tid < nparts ? tid : 0] >> 5) == 1u);
-        if (any_zr) {  // uniform
+        if (sh.plan_any_zr) {  // uniform
             emit_first_nonzero(th, sh);
             const int32_t nxinc = scan_nx_part1<G>(sh, tid, sh.wx);
             __syncthreads();
@@ -1102,9 +1101,21 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             // (timing ablation only)
         } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
             // all orders in one walk (every full block, every probe); without a run of >= 4 zeros in the
-            // block no partition can have one, so the zero-run costs are not needed
-            if (prm.zero_run && sh.best_hasrun) partition_fused<G, true>(th, sh, max_p, flush);
-            else partition_fused<G, false>(th, sh, max_p, flush);
+            // block no partition can have one, so the zero-run costs are not needed.  Narrow sums: every segment total
+            // stays below 2^32 (sum of u < 2^31, at most 35 bits of overhead per sample), so 32-bit LDS atomics on the
+            // low words of the (zeroed) 64-bit accumulators suffice.
+            auto flush32 = [&pm](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr) {
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                if (hr) atomicOr(&pm.segrun[idx], 1u);
+            };
+            auto flush32_nozr = [&pm](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+            };
+            if (prm.zero_run && sh.best_hasrun) partition_fused<G, true>(th, sh, max_p, flush32);
+            else partition_fused<G, false>(th, sh, max_p, flush32_nozr);
         } else {
             for (int p = 1; p <= max_p; ++p) {
                 if (pnarrow) {
@@ -1144,6 +1155,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 #endif
 }
 
+// (At 127 VGPRs x 4 waves per SIMD an analysis workgroup fills the register files of its CU, so every workgroup of the
+// streaming packer takes a whole CU away from the analysis: measured +25 us of kernel time per packer workgroup, hence
+// the packer's small grid.  The compiler offers no way to cap this kernel at 120.)
 template <class G>
 __global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
                                                   AnalyzeParams prm, int probe_class, uint32_t blk_offset,
