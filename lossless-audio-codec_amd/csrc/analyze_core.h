@@ -224,7 +224,7 @@ struct Smem {
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
-    uint32_t lbacc[11][2];         // per candidate: block sums of Thread::lb_g / lb_aux (pruning bound)
+    uint32_t lbacc[11][3];         // per candidate: block sums of Thread::lb_g / lb_aux / lb_ends (pruning bound)
     uint32_t has4[2];              // current candidate has a run of >= 4 zero residuals (zero-run mode possible)
     uint64_t wtotP[16];  // per-wave totals used by the block scans
     int32_t wtotZ[16];
@@ -259,6 +259,7 @@ struct Thread {
     uint32_t chasrun;
     uint32_t lb_g;    // sum over the chunk of bit_width(u)+1 (per-sample floor of any Rice code)
     uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16   (host form of the bound partials)
+    uint32_t lb_ends; // zero runs that end inside the chunk (a zero followed by a non-zero); the wave's count on the device
     uint32_t lb_wz, lb_wf;  // device form: the wave's counts of u == 0 (incl. positions beyond the slot) and u == 4
     uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
 };
@@ -535,32 +536,39 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
     // needs no special case for zero.  th.lb_g then lacks the wave's zero count, which the driver subtracts once per
     // wave (lb_wz); lb_wz / lb_wf are wave-uniform and count the positions beyond the slot as zeros.
     {
-        uint32_t c1sum = 0, wz = 0, wf = 0;
+        uint32_t c1sum = 0, wz = 0, wf = 0, we = 0;
+        unsigned long long zprev = 0;  // lanes whose previous sample was zero
 #pragma unroll
         for (int i = 0; i < G::CH; ++i) {
             c1sum += (uint32_t)__builtin_clz(u[i] | 1u);
-            wz += (uint32_t)__popcll(__ballot(u[i] == 0u));
+            const unsigned long long zcur = __ballot(u[i] == 0u);
+            wz += (uint32_t)__popcll(zcur);
+            we += (uint32_t)__popcll(zprev & ~zcur);  // scalar unit: a zero run ends here (positions beyond the slot are zeros: no end)
+            zprev = zcur;
             wf += (uint32_t)__popcll(__ballot(u[i] == 4u));
         }
         const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
         th.lb_g = 33u * (uint32_t)th.cnt + 32u * beyond - c1sum;
         th.lb_wz = wz;
         th.lb_wf = wf;
+        th.lb_ends = we;
         th.lb_aux = 0;
         return;
     }
 #endif
-    uint32_t clzsum = 0, nzero = 0, nfour = 0;
+    uint32_t clzsum = 0, nzero = 0, nfour = 0, ends = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         clzsum += (uint32_t)clz32(u[i]);
         nzero += 1u - (u[i] < 1u ? u[i] : 1u);           // 1 when u == 0
         const uint32_t x4 = u[i] ^ 4u;
         nfour += 1u - (x4 < 1u ? x4 : 1u);               // 1 when u == 4
+        if (i > 0 && u[i - 1] == 0u && u[i] != 0u) ++ends;
     }
     const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
     th.lb_g = 33u * (uint32_t)th.cnt - (clzsum - 32u * beyond);
     th.lb_aux = (nzero - beyond) + (nfour << 16);
+    th.lb_ends = ends;
 }
 
 // Part 2 (only for candidates that survive the pruning): the residual into LDS, the chunk sum, the last non-zero
@@ -743,19 +751,30 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     th.chasrun = hasrun;
 }
 
-// Exact lower bound on min(rice, static, zero-run, bin) of a candidate, from three block sums:
+// Exact lower bound on min(rice, static, zero-run, bin) of a candidate, from four block sums:
 //   any Rice code of u costs >= bit_width(u) + 1 bits whatever k is (k = bit_width(u)-1 or bit_width(u) attain it);
 //   bin costs the same or more except u == 4 (3 bits against 4);
-//   zero-run costs >= 2 + that for every non-zero sample and >= 0 for zeros (they may sit in runs).
+//   zero-run costs >= 2 + that for every non-zero sample; a maximal run of L zeros costs 3 L (or more) when L < 4 and
+//   4 + L / 4 (rounded down) as one token when L >= 4 (ref block/encoder.cpp:224-247).  With Z zeros in R >= max(E, 1)
+//   runs (E = run ends seen inside the threads' chunks) the cheapest arrangement is R - 1 single zeros and one long
+//   run: the zeros cost >= min(3 Z, 3 (R - 1) + 4 + (Z - R + 1) / 4).  An all-zero block meets the bound exactly.
 // A candidate whose bound is >= the best exact cost so far cannot win (the reference replaces the best only
 // on a strictly smaller cost, ref block/encoder.cpp:352-359), so its adaptive cost passes can be skipped.
-LACX_HD uint64_t candidate_lower_bound(uint32_t g_sum, uint32_t aux_sum, uint32_t n, int zero_run) {
+LACX_HD uint64_t candidate_lower_bound(uint32_t g_sum, uint32_t aux_sum, uint32_t ends, uint32_t n, int zero_run) {
     const uint32_t nzero = aux_sum & 0xFFFFu, n4 = aux_sum >> 16;
     const uint64_t lb_rice = g_sum;
     const uint64_t lb_bin = (uint64_t)g_sum - n4;
-    const uint64_t lb_zr = (uint64_t)g_sum - nzero + 2ull * (n - nzero);
     uint64_t lb = lb_rice < lb_bin ? lb_rice : lb_bin;
-    if (zero_run && lb_zr < lb) lb = lb_zr;
+    if (zero_run) {
+        uint64_t zeros = 0;
+        if (nzero != 0) {
+            const uint32_t runs = ends > 1u ? ends : 1u;  // ends <= nzero
+            const uint64_t shorts = 3ull * nzero, one_long = 3ull * (runs - 1u) + 4u + ((nzero - runs + 1u) >> 2);
+            zeros = shorts < one_long ? shorts : one_long;
+        }
+        const uint64_t lb_zr = (uint64_t)g_sum - nzero + 2ull * (n - nzero) + zeros;
+        if (lb_zr < lb) lb = lb_zr;
+    }
     return lb;
 }
 

@@ -903,7 +903,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
     }
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
-    if (tid < 22) (&sh.lbacc[0][0])[tid] = 0;
+    if (tid < 33) (&sh.lbacc[0][0])[tid] = 0;
     if (tid < 2) sh.has4[tid] = 0;
     if (tid == 0) sh.best_cand = -1;
     __syncthreads();
@@ -929,6 +929,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
             atomicAdd(&sh.lbacc[cand][0], g - th.lb_wz);
             atomicAdd(&sh.lbacc[cand][1], (th.lb_wz - beyond) + (th.lb_wf << 16));
+            atomicAdd(&sh.lbacc[cand][2], th.lb_ends);
         }
     }
     STAMP(2);
@@ -937,7 +938,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
         const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || (prm.debug_skip & 16u))) ||
                              (tid >= 1 && (prm.debug_skip & 64u)));
-        sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], n, prm.zero_run) << 4) | (uint64_t)tid)
+        sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], sh.lbacc[tid][2], n, prm.zero_run) << 4) | (uint64_t)tid)
                                  : ~0ull;
     }
     STAMP(5);

@@ -81,12 +81,13 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         scans_after_r(sh);
         plane_totals(sh, th);
         {
-            uint32_t g = 0, a = 0;
+            uint32_t g = 0, a = 0, e = 0;
             for (int t = 0; t < G::T; ++t) {
                 g += th[t].lb_g;
                 a += th[t].lb_aux;
+                e += th[t].lb_ends;
             }
-            if (!(force_wide & 4) && candidate_pruned(candidate_lower_bound(g, a, n, zero_run), cand, sh.best_bits, sh.best_cand)) continue;
+            if (!(force_wide & 4) && candidate_pruned(candidate_lower_bound(g, a, e, n, zero_run), cand, sh.best_bits, sh.best_cand)) continue;
         }
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
         const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
