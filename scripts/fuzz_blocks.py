@@ -14,6 +14,23 @@ n_streams = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 n_blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 600
 KINDS = ["music", "noise", "silence", "near_silence", "sparse", "ramp", "walk", "tone", "mixed"]
 STEREO = ["wide", "narrow", "identical", "anticorr", "independent"]
+
+
+def punch_gaps(x):
+    """Zero out random intervals (runs of every length class, many crossing the 16-sample chunk borders)."""
+    if x is None or x.size < 8:
+        return x
+    x = x.copy()
+    pos = 0
+    while pos < x.size:
+        keep = int(rng.choice([1, 1, 2, 3, 7, 16, 40, 300]))
+        gap = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 1000, 5000]))
+        pos += keep
+        x[pos:pos + gap] = 0
+        pos += gap
+    return x
+
+
 bad = 0
 t0 = time.time()
 for it in range(n_streams):
@@ -29,6 +46,8 @@ for it in range(n_streams):
         sh = int(rng.integers(1, bd - 1))
         left = (left >> sh).astype(np.int32)
         right = None if right is None else (right >> sh).astype(np.int32)
+    if rng.random() < 0.25:
+        left, right = punch_gaps(left), punch_gaps(right)
     zr, pt = bool(rng.random() < 0.85), bool(rng.random() < 0.85)
     enc = lacx.Encoder(12, sm, sr, bd)
     enc.set_zero_run_enabled(zr)
@@ -51,6 +70,8 @@ for it in range(n_blocks):
         x = (x >> int(rng.integers(1, 23))).astype(np.int32)
     if rng.random() < 0.1:
         x = (x.astype(np.int64) * 2).clip(-(1 << 24), 1 << 24).astype(np.int32)  # side-channel range
+    if rng.random() < 0.25:
+        x = punch_gaps(x)
     got = be.encode(x)
     want = oracleshim.block_encode(x)
     if got != want:

@@ -20,7 +20,7 @@ layout = pkg.lacx.PCM_INTERLEAVED_I16 if bd == 16 else pkg.lacx.PCM_INTERLEAVED_
 for it in range(iters):
     enc.encode_shard_pcm_device_view(d.data_ptr(), layout, 2, L.size, 0)
     lib.lacx_debug_stamps(buf)
-names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "-", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish"]
+names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "-", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish", "-"]
 idx = [i for i in range(32) if i != 22]
 tot = sum(buf[i] for i in idx)
 waves = buf[32]

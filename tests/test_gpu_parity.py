@@ -327,6 +327,51 @@ def test_random_sweep(gpu, oracle):
         assert be.encode(x) == oracle.block_encode(x), (it, n)
 
 
+def _punch_gaps(rng, x):
+    x = x.copy()
+    pos = 0
+    while pos < x.size:
+        pos += int(rng.choice([1, 1, 2, 3, 7, 16, 40, 300]))
+        gap = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 1000, 5000]))
+        x[pos:pos + gap] = 0
+        pos += gap
+    return x
+
+
+def test_zero_run_structures(gpu, oracle):
+    """Zero runs of every length class, inside and across the threads' 16-sample chunks, all-zero and almost-all-zero
+    blocks: the cases where the candidate pruning bound leans on its zero-run term (count of zeros, run ends)."""
+    rng = np.random.default_rng(77)
+    be = gpu.lacx.BlockEncoder()
+    blocks = [np.zeros(16384, np.int32), np.zeros(4097, np.int32), np.zeros(5, np.int32)]
+    one = np.zeros(16384, np.int32)
+    one[8000] = 1
+    blocks.append(one)
+    ends = np.zeros(16384, np.int32)
+    ends[0] = ends[-1] = -3
+    blocks.append(ends)
+    for period in (2, 4, 5, 16, 17, 64):  # one non-zero sample every `period`
+        x = np.zeros(16384, np.int32)
+        x[::period] = rng.integers(-4, 5, size=x[::period].size)
+        blocks.append(x)
+    for it in range(40):
+        n = int(rng.choice([257, 4096, 16384, int(rng.integers(300, 16385))]))
+        x, _ = gpu.synth.synth_pcm(n, 1, 24, 48000, seed=int(rng.integers(1, 10**6)), kind=str(rng.choice(["music", "noise", "walk", "sparse"])))
+        if rng.random() < 0.5:
+            x = (x >> int(rng.integers(8, 23))).astype(np.int32)
+        blocks.append(_punch_gaps(rng, x))
+    for i, x in enumerate(blocks):
+        assert be.encode(x) == oracle.block_encode(x), i
+    for it in range(6):
+        frames = int(rng.integers(20000, 60000))
+        bd = int(rng.choice([16, 24]))
+        left, right = gpu.synth.synth_pcm(frames, 2, bd, 48000, seed=int(rng.integers(1, 10**6)), kind="music", stereo="wide")
+        left, right = _punch_gaps(rng, left), _punch_gaps(rng, right)
+        if it & 1:
+            right = left.copy()  # side channel all zero
+        assert gpu.lacx.Encoder(12, 2, 48000, bd).encode(left, right) == oracle.encode(left, right, 48000, bd, 2, threads=8), it
+
+
 def test_begin_end_interface(gpu, oracle):
     """The two-halves interface (enqueue, collect later) with two encoders alternating: same bytes."""
     import torch

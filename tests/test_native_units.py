@@ -80,6 +80,38 @@ def test_simulated_kernel_plans_match_oracle(pkg, oracle, sim, kind):
     _check(sim, oracle, left[:16384], 0, True, False, 0)
 
 
+def test_pruning_bound_on_zero_run_structures(pkg, oracle, sim):
+    """The candidate pruning bound's zero-run term (zeros cost at least min(3 Z, 3 (R - 1) + 4 + (Z - R + 1) / 4) bits for
+    Z zeros in at least R runs): all-zero blocks, isolated non-zeros, periodic patterns and randomly punched gaps of
+    every run-length class, with the pruning on (0) and off (4) -- both must give the oracle's plan."""
+    rng = np.random.default_rng(5)
+    blocks = [np.zeros(16384, np.int32), np.zeros(300, np.int32)]
+    one = np.zeros(16384, np.int32)
+    one[8000] = 1
+    blocks.append(one)
+    for period in (2, 4, 5, 16, 17):
+        x = np.zeros(8192, np.int32)
+        x[::period] = rng.integers(-4, 5, size=x[::period].size)
+        blocks.append(x)
+    for it in range(10):
+        n = int(rng.integers(300, 16385))
+        x, _ = pkg.synth.synth_pcm(n, 1, 16, 48000, seed=int(rng.integers(1, 10**6)), kind=str(rng.choice(["music", "walk", "sparse"])))
+        if it & 1:
+            x = (x >> int(rng.integers(6, 14))).astype(np.int32)
+        x = x.copy()
+        pos = 0
+        while pos < x.size:
+            pos += int(rng.choice([1, 1, 2, 3, 7, 16, 40, 300]))
+            gap = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 1000]))
+            x[pos:pos + gap] = 0
+            pos += gap
+        blocks.append(x)
+    for x in blocks:
+        for wide in (0, 4):
+            _check(sim, oracle, x, 0, True, True, wide)
+    _check(sim, oracle, np.zeros(256, np.int32), 1, True, True, 0)
+
+
 def test_kernel_phases_clean_under_sanitizers():
     """The phase code the HIP kernels are built from, compiled for the host with AddressSanitizer + UBSan and run
     over block shapes and materials that reach every path (narrow / 64-bit, zero-run, bin, partitions, emit tiles)."""
