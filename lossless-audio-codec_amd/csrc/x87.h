@@ -61,154 +61,135 @@ LACX_HD xf80 xf_neg(xf80 a) {
     return a;
 }
 
+// All four operations below are written without data-dependent branches: one lane of the device kernel runs one
+// recursion, and 64 recursions that disagree about "same sign or not", "how far apart are the exponents", "carry or
+// not" would otherwise walk through every side of every branch one after the other.
+
 // Round (hi, guard/sticky from lo + extra sticky) to nearest even.
 LACX_HD xf80 xf_round(uint32_t s, int32_t e, uint64_t hi, uint64_t lo, bool sticky) {
-    const bool guard = (lo >> 63) != 0;
-    const bool st = sticky || ((lo << 1) != 0);
-    if (guard && (st || (hi & 1u))) {
-        ++hi;
-        if (hi == 0) {
-            hi = 0x8000000000000000ull;
-            ++e;
-        }
-    }
+    const uint64_t guard = lo >> 63;
+    const uint64_t st = (sticky || (lo << 1) != 0) ? 1u : 0u;
+    const uint64_t inc = guard & (st | (hi & 1u));
+    hi += inc;
+    const bool ovf = inc != 0 && hi == 0;  // carried out of bit 63
+    hi = ovf ? 0x8000000000000000ull : hi;
+    e += ovf ? 1 : 0;
     return xf80{hi, e, s};
 }
 
 LACX_HD xf80 xf_mul(xf80 a, xf80 b) {
-    if (a.m == 0 || b.m == 0) {
-        xf80 z = xf_zero();
-        z.s = a.s ^ b.s;
-        return z;
-    }
     uint64_t hi, lo;
     mul64x64(a.m, b.m, hi, lo);
-    int32_t e = a.e + b.e + 1;
-    if (!(hi >> 63)) {  // product in [2^126, 2^127): normalise by one bit
-        hi = (hi << 1) | (lo >> 63);
-        lo <<= 1;
-        e -= 1;
-    }
-    return xf_round(a.s ^ b.s, e, hi, lo, false);
+    const bool low = (hi >> 63) == 0;  // product in [2^126, 2^127): normalise by one bit
+    hi = low ? (hi << 1) | (lo >> 63) : hi;
+    lo = low ? lo << 1 : lo;
+    xf80 r = xf_round(a.s ^ b.s, a.e + b.e + (low ? 0 : 1), hi, lo, false);
+    const bool zero = a.m == 0 || b.m == 0;
+    r.m = zero ? 0 : r.m;
+    r.e = zero ? -(1 << 20) : r.e;
+    return r;
 }
 
 LACX_HD xf80 xf_add(xf80 a, xf80 b) {
-    if (b.m == 0) return a;
-    if (a.m == 0) return b;
-    // make |a| >= |b|
-    if (b.e > a.e || (b.e == a.e && b.m > a.m)) {
-        const xf80 t = a;
-        a = b;
-        b = t;
-    }
-    const int64_t d = (int64_t)a.e - (int64_t)b.e;
-    uint64_t bh, bl;
-    bool sticky = false;
-    if (d == 0) {
-        bh = b.m;
-        bl = 0;
-    } else if (d < 64) {
-        bh = b.m >> d;
-        bl = b.m << (64 - d);
-    } else if (d == 64) {
-        bh = 0;
-        bl = b.m;
-    } else if (d < 128) {
-        bh = 0;
-        bl = b.m >> (d - 64);
-        sticky = (b.m << (128 - d)) != 0;
-    } else {
-        bh = 0;
-        bl = 0;
-        sticky = true;
-    }
-    uint64_t rh, rl;
-    int32_t e = a.e;
-    if (a.s == b.s) {
-        rl = bl;  // a's low half is zero
-        rh = a.m + bh;
-        if (rh < a.m) {  // carry out of bit 127
-            sticky = sticky || (rl & 1u);
-            rl = (rl >> 1) | (rh << 63);
-            rh = (rh >> 1) | 0x8000000000000000ull;
-            ++e;
-        }
-        return xf_round(a.s, e, rh, rl, sticky);
-    }
-    // magnitude subtraction: (a.m:0) - (bh:bl) - (sticky ? 1 : 0)
-    rl = (uint64_t)0 - bl;
-    uint64_t borrow = bl != 0;
-    rh = a.m - bh - borrow;
-    if (sticky) {
-        if (rl == 0) --rh;
-        --rl;
-    }
-    if (rh == 0 && rl == 0) return xf_zero();  // exact cancellation -> +0
-    int lz;
-    if (rh) {
-        lz = clz64(rh);
-        if (lz) {
-            rh = (rh << lz) | (rl >> (64 - lz));
-            rl <<= lz;
-        }
-    } else {
-        lz = 64 + clz64(rl);
-        rh = rl << (lz - 64);
-        rl = 0;
-    }
-    e -= lz;
-    return xf_round(a.s, e, rh, rl, sticky);
+    // x = the operand of larger magnitude (a zero has the smallest exponent there is)
+    const bool swap = b.e > a.e || (b.e == a.e && b.m > a.m);
+    xf80 x, y;
+    x.m = swap ? b.m : a.m;
+    x.e = swap ? b.e : a.e;
+    x.s = swap ? b.s : a.s;
+    y.m = swap ? a.m : b.m;
+    y.e = swap ? a.e : b.e;
+    y.s = swap ? a.s : b.s;
+    // (yh:yl) = (y.m:0) >> d, sticky = whether ones were shifted out below bit 0 of yl
+    uint32_t d = (uint32_t)(x.e - y.e);
+    d = d > 128u ? 128u : d;
+    const uint32_t dl = d & 63u;
+    const uint64_t sh_r = y.m >> dl;
+    const uint64_t sh_l = (y.m << 1) << (63u - dl);  // y.m << (64 - dl); 0 for dl == 0
+    const bool lo_half = d < 64u, top = d >= 128u;
+    const uint64_t yh = lo_half ? sh_r : 0;
+    const uint64_t yl = lo_half ? sh_l : (top ? 0 : sh_r);
+    const bool sticky = !lo_half && (top ? y.m != 0 : sh_l != 0);
+    // same signs: (x.m:0) + (yh:yl), one bit to the right on a carry out of bit 127
+    uint64_t ah = x.m + yh, al = yl;
+    const bool carry = ah < x.m;
+    const bool st_add = sticky || (carry && (al & 1u));
+    al = carry ? (al >> 1) | (ah << 63) : al;
+    ah = carry ? (ah >> 1) | 0x8000000000000000ull : ah;
+    // different signs: (x.m:0) - (yh:yl) - (sticky ? 1 : 0), then to the left until bit 127 is set
+    const uint64_t stb = sticky ? 1u : 0u;
+    uint64_t sl = (uint64_t)0 - yl;
+    uint64_t sh = x.m - yh - (yl != 0 ? 1u : 0u) - (sl < stb ? 1u : 0u);
+    sl -= stb;
+    const bool cancelled = (sh | sl) == 0;
+    const uint32_t lz = sh ? (uint32_t)clz64(sh) : 64u + (uint32_t)clz64(sl);  // 128 when cancelled (not used then)
+    const uint32_t l = lz & 63u;
+    const uint64_t nh = lz < 64u ? (sh << l) | ((sl >> 1) >> (63u - l)) : sl << l;
+    const uint64_t nl = lz < 64u ? sl << l : 0;
+    const bool sub = x.s != y.s;
+    xf80 r = xf_round(x.s, sub ? x.e - (int32_t)lz : x.e + (carry ? 1 : 0), sub ? nh : ah, sub ? nl : al,
+                      sub ? sticky : st_add);
+    const bool zero_out = sub && cancelled;  // exact cancellation -> +0
+    r.m = zero_out ? 0 : r.m;
+    r.e = zero_out ? -(1 << 20) : r.e;
+    r.s = zero_out ? 0u : r.s;
+    const bool pass = y.m == 0;  // nothing to add: the other operand as it is (a when both are zero)
+    r.m = pass ? x.m : r.m;
+    r.e = pass ? x.e : r.e;
+    r.s = pass ? x.s : r.s;
+    return r;
 }
 
 LACX_HD xf80 xf_sub(xf80 a, xf80 b) { return xf_add(a, xf_neg(b)); }
 
+// floor((uh * 2^64 + ul) / D) and the remainder, for a 96-bit dividend below D * 2^32 (so the quotient fits 32 bits) and
+// a divisor with bit 63 set.  The quotient is estimated in double precision -- every rounding on the way is below
+// 2^-52 relative, so the estimate of a 32-bit quotient is off by far less than one -- and corrected by one unit either
+// way from the exact 128-bit remainder.
+LACX_HD uint32_t div96by64(uint32_t uh, uint64_t ul, uint64_t D, uint64_t* rem) {
+    const double num = (double)uh * 18446744073709551616.0 + (double)ul;
+    double est = num / (double)D;
+    est = est < 4294967295.0 ? est : 4294967295.0;
+    uint64_t q = (uint64_t)est;
+    // r = dividend - q * D  (q * D has 96 bits)
+    const uint64_t dlo = D & 0xFFFFFFFFull, dhi = D >> 32;
+    const uint64_t p0 = q * dlo, p1 = q * dhi;             // each < 2^64
+    const uint64_t pl = p0 + (p1 << 32);
+    const uint64_t ph = (p1 >> 32) + (pl < p0 ? 1u : 0u);
+    uint64_t rl = ul - pl;
+    int64_t rh = (int64_t)((uint64_t)uh - ph - (ul < pl ? 1u : 0u));
+    const bool neg = rh < 0;  // estimate one too high
+    {
+        const uint64_t t = rl + D;
+        rh += (neg && t < rl) ? 1 : 0;
+        rl = neg ? t : rl;
+        q -= neg ? 1u : 0u;
+    }
+    const bool ge = rh != 0 || rl >= D;  // estimate one too low
+    rl -= ge ? D : 0;
+    q += ge ? 1u : 0u;
+    *rem = rl;
+    return (uint32_t)q;
+}
+
 LACX_HD xf80 xf_div(xf80 a, xf80 b) {  // b != 0
-    if (a.m == 0) {
-        xf80 z = xf_zero();
-        z.s = a.s ^ b.s;
-        return z;
-    }
-    uint64_t q, rem;
-    int32_t e = a.e - b.e;
-    int iters;
-    if (a.m >= b.m) {
-        q = 1;
-        rem = a.m - b.m;
-        iters = 63;
-    } else {
-        q = 0;
-        rem = a.m;
-        iters = 64;
-        e -= 1;
-    }
-    for (int i = 0; i < iters; ++i) {
-        const bool carry = (rem >> 63) != 0;
-        rem <<= 1;
-        if (carry || rem >= b.m) {
-            rem -= b.m;
-            q = (q << 1) | 1u;
-        } else {
-            q <<= 1;
-        }
-    }
-    // round to nearest even on the remainder: compare 2*rem with b.m
-    bool up = false;
-    if (rem != 0) {
-        const uint64_t other = b.m - rem;  // > 0
-        if (rem > other) {
-            up = true;
-        } else if (rem == other) {
-            up = (q & 1u) != 0;
-        }
-    }
-    if (up) {
-        ++q;
-        if (q == 0) {
-            q = 0x8000000000000000ull;
-            ++e;
-        }
-    }
-    return xf80{q, e, a.s ^ b.s};
+    // quotient significand Q = floor(a.m * 2^(63 + t) / b.m) in [2^63, 2^64), t = [a.m < b.m]
+    const bool t = a.m < b.m;
+    const uint64_t nh = t ? a.m : a.m >> 1, nl = t ? 0 : a.m << 63;  // the 128-bit dividend
+    uint64_t r1, rem;
+    const uint32_t q1 = div96by64((uint32_t)(nh >> 32), (nh << 32) | (nl >> 32), b.m, &r1);
+    const uint32_t q0 = div96by64((uint32_t)(r1 >> 32), (r1 << 32) | (nl & 0xFFFFFFFFull), b.m, &rem);
+    uint64_t q = ((uint64_t)q1 << 32) | q0;
+    int32_t e = a.e - b.e - (t ? 1 : 0);
+    // round to nearest even on the remainder: compare 2 * rem with b.m
+    const uint64_t other = b.m - rem;  // > 0
+    const bool up = rem != 0 && (rem > other || (rem == other && (q & 1u)));
+    q += up ? 1u : 0u;
+    const bool ovf = up && q == 0;
+    q = ovf ? 0x8000000000000000ull : q;
+    e += ovf ? 1 : 0;
+    const bool zero = a.m == 0;
+    return xf80{zero ? 0 : q, zero ? -(1 << 20) : e, a.s ^ b.s};
 }
 
 // a < b

@@ -55,6 +55,16 @@ int main(int argc, char** argv) {
         long double x = rnd_ld(), y = rnd_ld();
         if (i % 5 == 0) y = x * (1.0L + std::ldexp((long double)((int)(rng() % 7) - 3), -(int)(rng() % 70)));
         if (i % 11 == 0) y = std::ldexp(x, -(int)(rng() % 140));
+        if (i % 13 == 0) {  // exponent distances around the 64- and 128-bit alignment borders, either way round
+            static const int kDist[] = {0, 1, 62, 63, 64, 65, 66, 126, 127, 128, 129, 130};
+            const int dist = kDist[rng() % 12];
+            y = std::ldexp(rnd_ld(), 0);
+            int ex, ey;
+            std::frexp(x, &ex);
+            std::frexp(y, &ey);
+            y = std::ldexp(y, ex - ey + ((rng() & 1) ? dist : -dist));
+        }
+        if (i % 97 == 0) x = 0.0L;  // zero operands (the divisor stays non-zero: xf_div requires it)
         if (y == 0.0L) y = 1.0L;
         xf80 a = from_ld(x), b = from_ld(y);
         volatile long double s = x + y, d = x - y, p = x * y, q = x / y;
@@ -63,6 +73,11 @@ int main(int argc, char** argv) {
         if (!same(xf_mul(a, b), p)) { printf("mul fail %La %La\n", x, y); ++fails; }
         if (!same(xf_div(a, b), q)) { printf("div fail %La %La\n", x, y); ++fails; }
         if (xf_lt(a, b) != (x < y)) { printf("lt fail %La %La\n", x, y); ++fails; }
+        if (i % 97 == 0) {  // ... and with the zero on the other side
+            volatile long double s2 = y + x, d2 = y - x, p2 = y * x;
+            if (!same(xf_add(b, a), s2) || !same(xf_sub(b, a), d2) || !same(xf_mul(b, a), p2) ||
+                !same(xf_add(a, a), 0.0L) || !same(xf_mul(a, a), 0.0L)) { printf("zero operand fail %La\n", y); ++fails; }
+        }
         // q15
         long double c = std::ldexp(x, -(int)(rng() % 80) + 2);
         if (i % 3 == 0) {  // near half-integers in Q15
