@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     // plane, consecutive lanes at consecutive slots -- and, for the 12 samples of history its first group needs,
     // reads groups 4t-3..4t-1 = planes 1..3 at index t-1: every access is conflict-free.
     __shared__ int4 s_plane[4][kIngestThreads + 1];
-    __shared__ int32_t s_win[12 + kProbe];
+    __shared__ __align__(16) int32_t s_win[3][12 + kProbe];
     __shared__ unsigned long long s_ac[13];
     __shared__ unsigned long long s_sum[3];
     __shared__ unsigned int s_bad;
@@ -437,17 +437,36 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     }
     if (used) reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + ch) * 13, tid);
 
-    // probe windows (per-block stereo, blocks above the full-comparison limit only): 256 samples each, lags
-    // inside the window only
+    // probe windows (per-block stereo, blocks above the full-comparison limit only): 256 samples each, lags inside the
+    // window only.  All threads stage the three windows; then wave w sums window w on its own -- four samples per lane,
+    // one wave reduction per lag, no workgroup-wide reduction and no further barrier.
     if (est && nb > (uint32_t)kFullCompareLimit) {
-        if (tid < 12) s_win[tid] = 0;
+        if (tid < 36) s_win[tid / 12][tid % 12] = 0;  // the samples before a window count as absent
         for (int w = 1; w <= 3; ++w) {
             const SlotGeom g = slot_geom(prm, blk, w * 4 + ch);
-            s_win[12 + tid] = slot_fetch(src, g.start + tid);  // kIngestThreads == kProbe
-            __syncthreads();
+            s_win[w - 1][12 + tid] = slot_fetch(src, g.start + tid);  // kIngestThreads == kProbe
+        }
+        __syncthreads();
+        const int wv = tid >> 6;
+        if (wv < 3) {  // uniform per wave
+            int32_t v[16];  // v[12 + i] = sample 4 * lane + i of the window
 #pragma unroll
-            for (int k = 0; k < 13; ++k) acc[k] = (int64_t)s_win[12 + tid] * (int64_t)s_win[12 + tid - k];
-            reduce13(acc, s_ac, acorr + ((size_t)blk * kSlotsPerBlock + w * 4 + ch) * 13, tid);
+            for (int c = 0; c < 4; ++c) {
+                const int4 q = *reinterpret_cast<const int4*>(&s_win[wv][4 * lane + 4 * c]);
+                v[4 * c] = q.x;
+                v[4 * c + 1] = q.y;
+                v[4 * c + 2] = q.z;
+                v[4 * c + 3] = q.w;
+            }
+            int64_t* out = acorr + ((size_t)blk * kSlotsPerBlock + (wv + 1) * 4 + ch) * 13;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                int64_t a = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a += (int64_t)v[12 + i] * (int64_t)v[12 + i - k];
+                const uint64_t t = wave_sum_u64((uint64_t)a);
+                if (lane == 0) out[k] = (int64_t)t;
+            }
         }
     }
 
