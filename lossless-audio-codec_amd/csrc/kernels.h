@@ -46,6 +46,24 @@ struct FuseArgs {
     uint32_t fuse_items = 0;                  // stream indices below this one take part (a small final block does not)
 };
 
+// The small results the host reads after a call (block plans, block table, totals, flags, time stamps) go back in ONE
+// kernel that stores them into pinned host memory, instead of one copy engine job each (about 5 us apiece, serialised).
+// Sizes in 32-bit words; dst are device-visible addresses of pinned host memory.
+struct GatherList {
+    static constexpr int kMax = 10;
+    const void* src[kMax];
+    void* dst[kMax];
+    uint32_t words[kMax];
+    int n = 0;
+    void add(const void* s, void* d, size_t bytes) {
+        src[n] = s;
+        dst[n] = d;
+        words[n] = (uint32_t)(bytes / 4);
+        ++n;
+    }
+};
+hipError_t launch_gather(const GatherList& g, hipStream_t stream);
+
 // Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).
 // ev: optional 5 events recorded at: start, after ingest+levinson, after probes+decide, after the
 // whole-block analysis kernel, end.  wait_before_full: optional event the whole-block analysis kernel waits for.
@@ -56,13 +74,19 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
 // Device-side emit of the analysed blocks of one chunk into the shard payload: k_offsets (block byte offsets), k_pack
 // (channel blocks the fused emit left in their staging slots: ws.emitted set) and k_emit (all others).
 // skip_emitted = false: k_emit emits everything (re-emit into a regrown buffer).
+// moved_total / shard_items: the streaming packer's count of channel blocks it has put in place and the number the shard
+// has; when they agree k_pack and k_emit have nothing to do and return at once (null: always look).
+// wait_before_pack: the packer's completion event; k_offsets does not depend on it and runs in front of the wait.
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                        const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
-                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted = true);
+                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted = true,
+                       const uint32_t* moved_total = nullptr, uint32_t shard_items = 0,
+                       hipEvent_t wait_before_pack = nullptr);
 
 // The streaming packer of the fused emit: runs beside the analysis kernels on its own stream and moves the staging
-// slots of stream indices [0, fuse_items) to their place in `out` as they are published.
+// slots of stream indices [0, fuse_items) to their place in `out` as they are published.  err_flag[1] receives the
+// number of channel blocks it has put in place.
 hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
                              unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream);
 

@@ -355,8 +355,13 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     const int ch = (int)chsel;
     const bool used = slot_channel_used(prm, ch);
     // forced mid/side still validates the left/right samples (ref lac/encoder.cpp:238-241)
-    const bool validate = ch < 2 && ch < prm.channels && prm.bit_depth != 0;
-    if (!used && !validate) return;  // uniform
+    // ... unless the container cannot hold an out-of-range value: 16-bit containers, packed 24-bit ones at depth 24
+    const bool container_bounds = prm.layout == PCM_INTERLEAVED_I16 || (prm.layout == PCM_INTERLEAVED_I24 && prm.bit_depth == 24);
+    const bool validate = ch < 2 && ch < prm.channels && prm.bit_depth != 0 && !container_bounds;
+    if (!used && !validate) {  // uniform
+        if (ch < 2 && threadIdx.x == 0) badidx[blk * 2 + ch] = 0xFFFFFFFFu;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nb = block_frames(prm, blk);
     const int64_t bstart = (int64_t)blk * kMaxBlock;
@@ -1376,7 +1381,9 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
                                                const unsigned long long* __restrict__ block_off,
                                                uint8_t* __restrict__ out, unsigned long long out_cap,
                                                uint32_t* __restrict__ err_flag,
-                                               const uint32_t* __restrict__ emitted) {
+                                               const uint32_t* __restrict__ emitted,
+                                               const uint32_t* __restrict__ moved_total, uint32_t shard_items) {
+    if (moved_total && *moved_total == shard_items) return;  // the streaming packer has moved everything (uniform)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
     __shared__ int32_t s_wx[16];
@@ -1432,12 +1439,14 @@ __global__ __launch_bounds__(kPackThreads) void k_stream_out(uint32_t total, int
                                                              const unsigned long long* __restrict__ ready_rec,
                                                              const uint8_t* __restrict__ slots, unsigned long long slot_stride,
                                                              uint8_t* __restrict__ out, unsigned long long out_cap,
-                                                             uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag) {
+                                                             uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag,
+                                                             uint32_t* __restrict__ moved_total) {
     __shared__ unsigned long long s_off, s_rec;
     __shared__ uint32_t s_state;  // 1 copy, 2 nothing to copy, 3 give up
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long running = 0;  // bytes of the stream indices [0, summed)   (wave 0 only)
     uint32_t summed = 0;
+    uint32_t moved = 0;  // stream indices this workgroup has put in place
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
         if (tid < 64) {  // wave 0, all lanes
             bool alive = true;
@@ -1501,10 +1510,13 @@ __global__ __launch_bounds__(kPackThreads) void k_stream_out(uint32_t total, int
                 const uint32_t fb = flag_byte ? 1u : 0u;
                 copy_slot_out(slots + (unsigned long long)i * slot_stride, out + off + fb, (uint32_t)bytes - fb, tid);
                 if (tid == 0) packed[i] = 1u;
+                ++moved;
             }
         }
         __syncthreads();
     }
+    // k_pack / k_emit behind this kernel return at once when every channel block of the shard was moved here
+    if (tid == 0 && moved) atomicAdd(moved_total, moved);
 }
 
 // k_pack: copies the channel blocks that the fused emit has written to their staging slots to their place in the shard
@@ -1520,7 +1532,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack(AnalyzeParams prm, const 
                                                        uint32_t* __restrict__ err_flag, const uint8_t* __restrict__ slots,
                                                        unsigned long long slot_stride,
                                                        const uint32_t* __restrict__ emitted,
-                                                       const uint32_t* __restrict__ packed) {
+                                                       const uint32_t* __restrict__ packed,
+                                                       const uint32_t* __restrict__ moved_total, uint32_t shard_items) {
+    if (moved_total && *moved_total == shard_items) return;  // the streaming packer has moved everything (uniform)
     const int tid = threadIdx.x;
     const uint32_t per = prm.channels == 2 ? 2u : 1u;
     for (uint32_t work = blockIdx.x; work < prm.num_blocks * per; work += gridDim.x) {
@@ -1542,6 +1556,16 @@ __global__ __launch_bounds__(kPackThreads) void k_pack(AnalyzeParams prm, const 
     }
     if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
     copy_slot_out(slots + idx * slot_stride, out + off, count, tid);
+    }
+}
+
+// k_gather: see GatherList (kernels.h).
+__global__ __launch_bounds__(256) void k_gather(GatherList g) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, gsz = gridDim.x * 256u;
+    for (int k = 0; k < g.n; ++k) {
+        const uint32_t* __restrict__ s = static_cast<const uint32_t*>(g.src[k]);
+        uint32_t* __restrict__ d = static_cast<uint32_t*>(g.dst[k]);
+        for (uint32_t i = gid; i < g.words[k]; i += gsz) d[i] = s[i];
     }
 }
 
@@ -1598,7 +1622,8 @@ static hipError_t ensure_kernel_attrs() {
 hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
                        const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
-                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted) {
+                       hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted, const uint32_t* moved_total,
+                       uint32_t shard_items, hipEvent_t wait_before_pack) {
     const hipError_t attr_err = ensure_kernel_attrs();
     if (attr_err != hipSuccess) return attr_err;
     const uint32_t nb = prm.num_blocks;
@@ -1613,17 +1638,31 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
         const hipError_t re = hipEventRecord(offsets_done, stream);
         if (re != hipSuccess) return re;
     }
+    if (wait_before_pack) {  // the streaming packer has to be through before anybody looks at what it left behind
+        const hipError_t we = hipStreamWaitEvent(stream, wait_before_pack, 0);
+        if (we != hipSuccess) return we;
+    }
     if (skip_emitted && ws.slots) {
         const uint32_t work = nb * (prm.channels == 2 ? 2u : 1u);
         hipLaunchKernelGGL(k_pack, dim3(work < (uint32_t)kPackGrid ? work : (uint32_t)kPackGrid), dim3(kPackThreads), 0, stream, prm, ws.bplans,
                            ws.plans, ws.block_off, out, out_cap, ws.err_flag, (const uint8_t*)ws.slots, ws.slot_stride,
-                           (const uint32_t*)ws.emitted, (const uint32_t*)ws.packed);
+                           (const uint32_t*)ws.emitted, (const uint32_t*)ws.packed, moved_total, shard_items);
     }
     const uint32_t emit_work = nb * (prm.channels == 2 ? 2u : 1u);
     const bool leftovers_only = skip_emitted && ws.slots;  // behind the fused emit
     hipLaunchKernelGGL(k_emit<GFull>, dim3(leftovers_only && emit_work > 64u ? 64u : emit_work), dim3(GFull::T),
                        sizeof(EmitMem<GFull>), stream, d_left, d_right, prm, ws.bplans, ws.plans, ws.block_off,
-                       out, out_cap, ws.err_flag, skip_emitted ? (const uint32_t*)ws.emitted : (const uint32_t*)nullptr);
+                       out, out_cap, ws.err_flag, skip_emitted ? (const uint32_t*)ws.emitted : (const uint32_t*)nullptr,
+                       leftovers_only ? moved_total : (const uint32_t*)nullptr, shard_items);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const GatherList& g, hipStream_t stream) {
+    if (g.n == 0) return hipSuccess;
+    uint32_t most = 0;
+    for (int k = 0; k < g.n; ++k) most = g.words[k] > most ? g.words[k] : most;
+    const uint32_t grid = most <= 256u ? 1u : (most + 255u) / 256u > 32u ? 32u : (most + 255u) / 256u;
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, stream, g);
     return hipGetLastError();
 }
 
@@ -1636,7 +1675,7 @@ hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorksp
     hipLaunchKernelGGL(k_stream_out, dim3(fuse_items < (uint32_t)grid ? fuse_items : (uint32_t)grid),
                        dim3(kPackThreads), 0, stream, fuse_items, autost, nap, (const unsigned long long*)ws.size_rec,
                        (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots, ws.slot_stride, out, out_cap,
-                       ws.packed, err_flag);
+                       ws.packed, err_flag, err_flag + 1);
     return hipGetLastError();
 }
 
@@ -1683,7 +1722,7 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
                            (unsigned long long*)nullptr, FuseArgs{});
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
-    if (autost) {
+    if (autost && last_frames <= (uint64_t)kFullCompareLimit) {  // phase 2 only concerns such a final block
         hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }

@@ -800,28 +800,35 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
         const AnalyzeParams& prm = cx.prm;
         const int32_t *cl = cx.left, *cr = cx.right;
         const DeviceWorkspace& w = cx.w;
-        if (fuse_items && !std::getenv("LACX_NO_PACKER")) HIP_TRY(e, hipStreamWaitEvent(s, e->pack_done, 0), "stream wait");
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
+        const bool packer_counts = fuse_items && !std::getenv("LACX_NO_PACKER");
         HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
-                               e->copied[c], s), "emit launch");
+                               e->copied[c], s, true, packer_counts ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
+                               nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr), "emit launch");
         prev_end = w.block_off + ck.count;
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
-        HIP_TRY(e, hipMemcpyAsync(e->h_bplans + ck.first, w.bplans, (size_t)ck.count * sizeof(BlockPlan),
-                                  hipMemcpyDeviceToHost, s), "D2H block plans");
-        HIP_TRY(e, hipMemcpyAsync(e->h_table + (size_t)ck.first * 2, w.table, (size_t)ck.count * 2 * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s), "D2H table");
-        HIP_TRY(e, hipMemcpyAsync(&e->h_totals[c], w.block_off + ck.count, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, s), "D2H total");
-        HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
-        if (c + 1 == chunks.size())
-            HIP_TRY(e, hipMemcpyAsync(&e->h_err[kMaxChunks], e->ws.err_flag + kMaxChunks, sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, s), "D2H err");
+        // what the host reads afterwards, in one kernel that stores into the pinned buffers
+        GatherList g;
+        auto mapped = [](auto* host) -> decltype(host) {  // the address the device uses for a pinned host buffer
+            void* d = nullptr;
+            return hipHostGetDevicePointer(&d, host, 0) == hipSuccess ? static_cast<decltype(host)>(d) : nullptr;
+        };
+        BlockPlan* m_bplans = mapped(e->h_bplans);
+        uint32_t *m_table = mapped(e->h_table), *m_err = mapped(e->h_err), *m_emitted = fused ? mapped(e->h_emitted) : nullptr;
+        unsigned long long *m_totals = mapped(e->h_totals), *m_tspan = mapped(e->h_tspan);
+        if (!m_bplans || !m_table || !m_err || !m_totals || !m_tspan || (fused && !m_emitted))
+            return fail(e, LACX_E_RUNTIME, "hipHostGetDevicePointer failed");
+        g.add(w.bplans, m_bplans + ck.first, (size_t)ck.count * sizeof(BlockPlan));
+        g.add(w.table, m_table + (size_t)ck.first * 2, (size_t)ck.count * 2 * sizeof(uint32_t));
+        g.add(w.block_off + ck.count, &m_totals[c], sizeof(unsigned long long));
+        g.add(w.err_flag, &m_err[c], sizeof(uint32_t));
+        if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], sizeof(uint32_t));
         if (fused)
-            HIP_TRY(e, hipMemcpyAsync(e->h_emitted + (size_t)ck.first * channels, e->ws.packed + (size_t)ck.first * channels,
-                                      (size_t)ck.count * channels * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H packed");
-        HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[c], w.t_first, sizeof(unsigned long long), hipMemcpyDeviceToHost, s), "D2H t");
-        HIP_TRY(e, hipMemcpyAsync(&e->h_tspan[kMaxChunks + c], w.t_last, sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, s), "D2H t");
+            g.add(e->ws.packed + (size_t)ck.first * channels, m_emitted + (size_t)ck.first * channels,
+                  (size_t)ck.count * channels * sizeof(uint32_t));
+        g.add(w.t_first, &m_tspan[c], sizeof(unsigned long long));
+        g.add(w.t_last, &m_tspan[kMaxChunks + c], sizeof(unsigned long long));
+        HIP_TRY(e, launch_gather(g, s), "gather launch");
         HIP_TRY(e, hipEventRecord(e->done[c], s), "event record");
     }
     e->pend.active = true;

@@ -146,9 +146,9 @@ LACX_HD xf80 xf_sub(xf80 a, xf80 b) { return xf_add(a, xf_neg(b)); }
 // a divisor with bit 63 set.  The quotient is estimated in double precision -- every rounding on the way is below
 // 2^-52 relative, so the estimate of a 32-bit quotient is off by far less than one -- and corrected by one unit either
 // way from the exact 128-bit remainder.
-LACX_HD uint32_t div96by64(uint32_t uh, uint64_t ul, uint64_t D, uint64_t* rem) {
+LACX_HD uint32_t div96by64(uint32_t uh, uint64_t ul, uint64_t D, double rcp_d, uint64_t* rem) {
     const double num = (double)uh * 18446744073709551616.0 + (double)ul;
-    double est = num / (double)D;
+    double est = num * rcp_d;  // rcp_d = 1 / (double)D, rounded
     est = est < 4294967295.0 ? est : 4294967295.0;
     uint64_t q = (uint64_t)est;
     // r = dividend - q * D  (q * D has 96 bits)
@@ -177,8 +177,9 @@ LACX_HD xf80 xf_div(xf80 a, xf80 b) {  // b != 0
     const bool t = a.m < b.m;
     const uint64_t nh = t ? a.m : a.m >> 1, nl = t ? 0 : a.m << 63;  // the 128-bit dividend
     uint64_t r1, rem;
-    const uint32_t q1 = div96by64((uint32_t)(nh >> 32), (nh << 32) | (nl >> 32), b.m, &r1);
-    const uint32_t q0 = div96by64((uint32_t)(r1 >> 32), (r1 << 32) | (nl & 0xFFFFFFFFull), b.m, &rem);
+    const double rcp_d = 1.0 / (double)b.m;
+    const uint32_t q1 = div96by64((uint32_t)(nh >> 32), (nh << 32) | (nl >> 32), b.m, rcp_d, &r1);
+    const uint32_t q0 = div96by64((uint32_t)(r1 >> 32), (r1 << 32) | (nl & 0xFFFFFFFFull), b.m, rcp_d, &rem);
     uint64_t q = ((uint64_t)q1 << 32) | q0;
     int32_t e = a.e - b.e - (t ? 1 : 0);
     // round to nearest even on the remainder: compare 2 * rem with b.m
@@ -194,23 +195,11 @@ LACX_HD xf80 xf_div(xf80 a, xf80 b) {  // b != 0
 
 // a < b
 LACX_HD bool xf_lt(xf80 a, xf80 b) {
-    const bool az = a.m == 0, bz = b.m == 0;
-    if (az && bz) return false;
-    if (az) return b.s == 0;
-    if (bz) return a.s != 0;
-    if (a.s != b.s) return a.s != 0;
-    bool mag_lt;  // |a| < |b|
-    bool mag_eq = false;
-    if (a.e != b.e) {
-        mag_lt = a.e < b.e;
-    } else if (a.m != b.m) {
-        mag_lt = a.m < b.m;
-    } else {
-        mag_lt = false;
-        mag_eq = true;
-    }
-    if (mag_eq) return false;
-    return a.s ? !mag_lt : mag_lt;
+    // a zero has the smallest exponent and significand there are, and counts as positive whatever its sign bit says
+    const bool mag_lt = a.e < b.e || (a.e == b.e && a.m < b.m);  // |a| < |b|
+    const bool mag_gt = b.e < a.e || (a.e == b.e && b.m < a.m);
+    const bool na = a.s != 0 && a.m != 0, nb = b.s != 0 && b.m != 0;
+    return na != nb ? na : (na ? mag_gt : mag_lt);
 }
 
 // static_cast<double>(a) then std::round(c * 32768.0), clamped to int16

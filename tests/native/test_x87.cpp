@@ -76,7 +76,8 @@ int main(int argc, char** argv) {
         if (i % 97 == 0) {  // ... and with the zero on the other side
             volatile long double s2 = y + x, d2 = y - x, p2 = y * x;
             if (!same(xf_add(b, a), s2) || !same(xf_sub(b, a), d2) || !same(xf_mul(b, a), p2) ||
-                !same(xf_add(a, a), 0.0L) || !same(xf_mul(a, a), 0.0L)) { printf("zero operand fail %La\n", y); ++fails; }
+                !same(xf_add(a, a), 0.0L) || !same(xf_mul(a, a), 0.0L) || xf_lt(b, a) != (y < x) || xf_lt(a, a) ||
+                xf_lt(xf_neg(a), b) != (x < y) || xf_lt(b, xf_neg(a)) != (y < x)) { printf("zero operand fail %La\n", y); ++fails; }
         }
         // q15
         long double c = std::ldexp(x, -(int)(rng() % 80) + 2);
