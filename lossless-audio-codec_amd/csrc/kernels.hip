@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 // streaming packer takes a whole CU away from the analysis: measured +25 us of kernel time per packer workgroup, hence
 // the packer's small grid.  The compiler offers no way to cap this kernel at 120.)
 template <class G>
-__global__ __launch_bounds__(G::T) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
+__global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
                                                   AnalyzeParams prm, int probe_class, uint32_t blk_offset,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
@@ -1400,8 +1400,10 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
 }
 
 // `count` bytes from a staging slot (16-byte aligned, padded by 16 readable bytes) to dst (any alignment): 16-byte
-// stores on 16-byte boundaries of the destination, the ragged head and tail bytewise.  One 256-thread workgroup.
+// stores on 16-byte boundaries of the destination, the ragged head and tail bytewise.  NT cooperating threads (one
+// 256-thread workgroup in k_pack, one wave in the streaming packer).
 constexpr int kPackThreads = 256;
+template <int NT = kPackThreads, int UNROLL = 4>
 __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t count,
                                               int tid) {
     const uint32_t* sw32 = reinterpret_cast<const uint32_t*>(src);
@@ -1412,7 +1414,8 @@ __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, u
     {
         const uint32_t r = head & 3u, j0 = head >> 2;
         uint4* vdst = reinterpret_cast<uint4*>(dst + head);
-        for (uint32_t v = tid; v < nvec; v += kPackThreads) {
+#pragma unroll UNROLL
+        for (uint32_t v = tid; v < nvec; v += NT) {
             const uint32_t j = j0 + 4u * v;
             uint32_t w[5];
 #pragma unroll
@@ -1429,94 +1432,93 @@ __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, u
     if (t0 + (uint32_t)tid < count) dst[t0 + tid] = src[t0 + tid];
 }
 
-// k_stream_out: the streaming packer (see "Fused emit + streaming packer" above).  kStreamGrid workgroups; workgroup w
-// moves the stream indices w, w + grid, ...; each keeps its own running byte offset by summing the size records of
-// every index in order (64 per load round).  total: number of fusable stream indices of the shard.
-constexpr int kStreamGrid = 8;  // measured: more workgroups keep more PCIe writes in flight and slow the analysis kernel down
+// k_stream_out: the streaming packer (see "Fused emit + streaming packer" above).  Every WAVE is a packer of its own:
+// wave u of U moves the stream indices u, u + U, ... and keeps its own running byte offset by summing the size records
+// of every index in order (64 per load round); no barrier, no shared memory.  The waves come as 1024-thread workgroups
+// because of where they run: an analysis workgroup fills the register files of its CU, so a packer workgroup takes a
+// whole CU away from the analysis however small it is -- sixteen packer waves on one CU cost the analysis one CU, eight
+// 256-thread workgroups cost it eight.  One CU moves about 16 GB/s into pinned host memory however many stores it keeps
+// in flight, so the 10 min stream's 57 MB in 2.5 ms need two.  Measured (ms per step: 16/48 music, 16/48 mixed,
+// 24/96 mixed): 8 x 256 threads 3.15 / 4.15 / 8.33; 1 x 1024 4.02 (packer too slow) / 3.99 / -; 2 x 1024 3.12 / 4.02 /
+// 8.15; 3 x 1024 3.27 / 3.98 / 8.22; 4 x 1024 3.29 / 3.96 / 8.17.  total: fusable stream indices of the shard.
+#ifndef LACX_STREAM_UNROLL
+#define LACX_STREAM_UNROLL 8
+#endif
+constexpr int kStreamGrid = 2;
+constexpr int kStreamThreads = 1024;
 constexpr unsigned long long kStreamTimeoutTicks = 2000000ull;  // 20 ms of the 100 MHz clock without the awaited record
-__global__ __launch_bounds__(kPackThreads) void k_stream_out(uint32_t total, int autost, int nap,
-                                                             const unsigned long long* __restrict__ size_rec,
-                                                             const unsigned long long* __restrict__ ready_rec,
-                                                             const uint8_t* __restrict__ slots, unsigned long long slot_stride,
-                                                             uint8_t* __restrict__ out, unsigned long long out_cap,
-                                                             uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag,
-                                                             uint32_t* __restrict__ moved_total) {
-    __shared__ unsigned long long s_off, s_rec;
-    __shared__ uint32_t s_state;  // 1 copy, 2 nothing to copy, 3 give up
-    const int tid = threadIdx.x, lane = tid & 63;
-    unsigned long long running = 0;  // bytes of the stream indices [0, summed)   (wave 0 only)
+__global__ __launch_bounds__(kStreamThreads) void k_stream_out(uint32_t total, int autost, int nap,
+                                                               const unsigned long long* __restrict__ size_rec,
+                                                               const unsigned long long* __restrict__ ready_rec,
+                                                               const uint8_t* __restrict__ slots, unsigned long long slot_stride,
+                                                               uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                               uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag,
+                                                               uint32_t* __restrict__ moved_total) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t unit = blockIdx.x * (uint32_t)(kStreamThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t units = gridDim.x * (uint32_t)(kStreamThreads / 64);
+    unsigned long long running = 0;  // bytes of the stream indices [0, summed)
     uint32_t summed = 0;
-    uint32_t moved = 0;  // stream indices this workgroup has put in place
-    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
-        if (tid < 64) {  // wave 0, all lanes
-            bool alive = true;
-            unsigned long long mine = 0;
-            // sizes of [summed, i], 64 records per round; the last one is this index's own
-            while (alive && summed <= i) {
-                const uint32_t j = summed + (uint32_t)lane;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned long long v;
-                for (;;) {
-                    v = (j <= i) ? rec_load(&size_rec[j]) : kRecValid;
-                    if (__ballot((v & kRecValid) == 0ull) == 0ull) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
-                        alive = false;
-                        break;
-                    }
-                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
+    uint32_t moved = 0;  // stream indices this wave has put in place
+    for (uint32_t i = unit; i < total; i += units) {
+        bool alive = true;
+        unsigned long long mine = 0;
+        // sizes of [summed, i], 64 records per round; the last one is this index's own
+        while (alive && summed <= i) {
+            const uint32_t j = summed + (uint32_t)lane;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long v;
+            for (;;) {
+                v = (j <= i) ? rec_load(&size_rec[j]) : kRecValid;
+                if (__ballot((v & kRecValid) == 0ull) == 0ull) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
+                    alive = false;
+                    break;
                 }
-                if (!alive) break;
-                const uint32_t cnt = (i - summed + 1u) < 64u ? (i - summed + 1u) : 64u;
-                const bool last_round = summed + cnt == i + 1u;
-                // everything but this index's own record goes into the running offset
-                const bool take = (uint32_t)lane < cnt && !(last_round && (uint32_t)lane == cnt - 1u);
-                running += wave_sum_u64(take ? (v & kRecBytesMask) : 0ull);
-                if (last_round) mine = __shfl(v, (int)cnt - 1, 64);
-                summed += cnt;
+                for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
             }
-            unsigned long long ready = 0;
-            if (alive) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    ready = rec_load(&ready_rec[i]);
-                    if (ready != 0ull) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
-                        alive = false;
-                        break;
-                    }
-                    for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            if (alive && ready == 1ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (tid == 0) {
-                s_state = !alive ? 3u : (ready == 1ull ? 1u : 2u);
-                s_off = running;
-                s_rec = mine;
-            }
-            running += mine & kRecBytesMask;  // this index is accounted for whatever happens to its bytes
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier releases
+            if (!alive) break;
+            const uint32_t cnt = (i - summed + 1u) < 64u ? (i - summed + 1u) : 64u;
+            const bool last_round = summed + cnt == i + 1u;
+            // everything but this index's own record goes into the running offset
+            const bool take = (uint32_t)lane < cnt && !(last_round && (uint32_t)lane == cnt - 1u);
+            running += wave_sum_u64(take ? (v & kRecBytesMask) : 0ull);
+            if (last_round) mine = __shfl(v, (int)cnt - 1, 64);
+            summed += cnt;
         }
-        __syncthreads();
-        const uint32_t state = s_state;
-        if (state == 3u) break;  // uniform: a producer went missing; k_pack / k_emit move what is left
-        if (state == 1u) {
-            const unsigned long long rec = s_rec, off = s_off;
+        unsigned long long ready = 0;
+        if (alive) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                ready = rec_load(&ready_rec[i]);
+                if (ready != 0ull) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamTimeoutTicks) {
+                    alive = false;
+                    break;
+                }
+                for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        if (!alive) break;  // wave-uniform: a producer went missing; k_pack / k_emit move what is left
+        const unsigned long long off = running, rec = mine;
+        running += mine & kRecBytesMask;  // this index is accounted for whatever happens to its bytes
+        if (ready == 1ull) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const unsigned long long bytes = rec & kRecBytesMask;
             const bool flag_byte = autost && (i & 1u) == 0u;
             if (off + bytes > out_cap) {  // the destination was sized from an estimate: report, write nothing
-                if (tid == 0) atomicOr(err_flag, 2u);
+                if (lane == 0) atomicOr(err_flag, 2u);
             } else {
-                if (flag_byte && tid == 0) out[off] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+                if (flag_byte && lane == 0) out[off] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
                 const uint32_t fb = flag_byte ? 1u : 0u;
-                copy_slot_out(slots + (unsigned long long)i * slot_stride, out + off + fb, (uint32_t)bytes - fb, tid);
-                if (tid == 0) packed[i] = 1u;
+                copy_slot_out<64, LACX_STREAM_UNROLL>(slots + (unsigned long long)i * slot_stride, out + off + fb, (uint32_t)bytes - fb, lane);
+                if (lane == 0) packed[i] = 1u;
                 ++moved;
             }
         }
-        __syncthreads();
     }
     // k_pack / k_emit behind this kernel return at once when every channel block of the shard was moved here
-    if (tid == 0 && moved) atomicAdd(moved_total, moved);
+    if (lane == 0 && moved) atomicAdd(moved_total, moved);
 }
 
 // k_pack: copies the channel blocks that the fused emit has written to their staging slots to their place in the shard
@@ -1672,8 +1674,7 @@ hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorksp
     int nap = 1, grid = kStreamGrid;  // tuning knobs
     if (const char* v = std::getenv("LACX_PACK_NAP")) nap = std::atoi(v) > 0 ? std::atoi(v) : 1;
     if (const char* v = std::getenv("LACX_PACK_GRID")) grid = std::atoi(v) > 0 ? std::atoi(v) : grid;
-    hipLaunchKernelGGL(k_stream_out, dim3(fuse_items < (uint32_t)grid ? fuse_items : (uint32_t)grid),
-                       dim3(kPackThreads), 0, stream, fuse_items, autost, nap, (const unsigned long long*)ws.size_rec,
+    hipLaunchKernelGGL(k_stream_out, dim3((uint32_t)grid), dim3(kStreamThreads), 0, stream, fuse_items, autost, nap, (const unsigned long long*)ws.size_rec,
                        (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots, ws.slot_stride, out, out_cap,
                        ws.packed, err_flag, err_flag + 1);
     return hipGetLastError();
