@@ -1073,22 +1073,32 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     STAMP(15);
     // ---- partition search on the winning residual -------------------------------------------
     const int best = sh.best_cand;
-    phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
     int max_p = 0;
     if (prm.partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
     const int nseg = max_p > 0 ? ((2 << max_p) - 2) : 0;
     PartMem<G>& pm = sh.xp.part;
-    {
-        ScanRegs<G> sr;
-        scan_pz_part1(sh, tid, sr);
-        __syncthreads();
-        // the partition scratch aliases the samples: clear it only now that every thread is past phase_r
+    auto clear_partition_scratch = [&]() {  // aliases the staged samples: only once every thread is done with them
         for (int i = tid; i < 15 * (G::NG + 1); i += G::T) (&pm.grp[0][0])[i] = 0;
         for (int i = tid; i < nseg; i += G::T) {
             pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
             pm.segrun[i] = 0;
         }
         if (tid <= G::MAXP) pm.pbits[tid] = 0;
+    };
+    if (best == pending && !(prm.debug_skip & 16384u)) {
+        // The winner is the candidate evaluated last (usually the only one): its residual is still in sh.u, with the
+        // micro-window flags of phase A in bits 30/31, its prefix sums in tabP / tabNZ, its plane counts in th.cs.
+        // Strip the flags; nobody reads the staged samples any more (the last barrier of the search is behind us).
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) sh.u[i * G::T + tid] &= 0x3FFFFFFFu;
+        clear_partition_scratch();
+        __syncthreads();
+    } else {
+        phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        __syncthreads();
+        clear_partition_scratch();
         scan_pz_part2(sh, tid, sr);
         __syncthreads();
     }
