@@ -490,7 +490,7 @@ def worker(args) -> int:
             "api_call": round(mean("api_ms"), 3),
         },
         "fused_emit": {"streamed_out_beside_the_analysis": int(tm.emit_direct), "channel_blocks": int(tm.full_slots)},
-        "device_analysis_msamples_s": round(frames * 2 / (mean("analysis_ms") / 1e3) / 1e6, 3),
+        "device_analysis_msamples_s": round(frames * 2 / (max(mean("analysis_ms"), 1e-9) / 1e3) / 1e6, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,

@@ -4,7 +4,7 @@
 //   k_ingest    one workgroup per (block, channel): sample-range validation, the proxy sums of
 //               estimate_stereo_mode, exact 13-lag int64 autocorrelation of the whole block and of the
 //               3 probe windows                             (ref lac/encoder.cpp:82-102,126-178; lpc.cpp:80-96)
-//   k_stereo    one lane per block: LR/MS estimate -> BlockPlan, need masks (ref lac/encoder.cpp:179-196)
+//   k_stereo    sixteen lanes per block: LR/MS estimate -> BlockPlan, need masks (ref lac/encoder.cpp:179-196)
 //   k_levinson  one lane per slot: Levinson-Durbin in software x87 extended precision -> Q15 sets
 //                                                           (ref lpc.cpp:98-186)
 //   k_analyze<4,64>     one wave per probe slot of an "uncertain" block (ref lac/encoder.cpp:341-354)
@@ -281,7 +281,7 @@ __device__ __forceinline__ SlotSrc slot_src(const AnalyzeParams& prm, const int3
 //   * the three 256-frame probe windows (lac/encoder.cpp:343-346) as three more small passes;
 //   * the channel's three proxy sums of estimate_stereo_mode (lac/encoder.cpp:146-178) and the sample
 //     range validation (lac/encoder.cpp:82-102).
-// k_stereo: one lane per block turns the 12 sums into the LR/MS estimate + need masks.
+// k_stereo: sixteen lanes per block turn the 12 sums into the LR/MS estimate + need masks.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t zz64(int64_t v) {  // ref lac/encoder.cpp:38-41
     return v >= 0 ? ((uint64_t)v << 1) : ((((uint64_t)(-(v + 1))) << 1) | 1u);
@@ -290,8 +290,9 @@ __device__ __forceinline__ uint64_t zz64(int64_t v) {  // ref lac/encoder.cpp:38
 __device__ __forceinline__ uint64_t approx_rice_bits(uint64_t sum, uint64_t count) {  // ref lac/encoder.cpp:43-57
     if (count == 0) return 0;
     const uint64_t mean = (sum + (count >> 1)) / count;
-    uint32_t k = 0;
-    while (k < 31u && ((uint64_t)1 << k) < mean) ++k;
+    // the smallest k <= 31 with 2^k >= mean (the reference counts up from 0)
+    uint32_t k = mean <= 1u ? 0u : 64u - (uint32_t)__clzll((long long)(mean - 1u));
+    k = k > 31u ? 31u : k;
     return (sum >> k) + count * (uint64_t)(k + 1u);  // saturation is unreachable for <= 2^14 samples of <= 2^27
 }
 
@@ -495,13 +496,37 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     }
 }
 
+// Sixteen lanes per block, four blocks per wave: lanes 0..11 of a block turn one of its 12 proxy sums into bits (one
+// 64-bit division each instead of a chain of twelve), lane 0 of the block decides.
+constexpr int kStereoLanes = 16;
 __global__ __launch_bounds__(64) void k_stereo(AnalyzeParams prm, const unsigned long long* __restrict__ sums,
                                                const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
                                                uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
-    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= prm.num_blocks) return;
-    const uint32_t nb = block_frames(prm, blk);
+    const int tid = threadIdx.x, sub = tid & (kStereoLanes - 1), grp = tid & ~(kStereoLanes - 1);
+    const uint32_t blk = blockIdx.x * (64 / kStereoLanes) + (uint32_t)(tid / kStereoLanes);
+    const bool live = blk < prm.num_blocks;  // every lane stays for the shuffles
+    const uint32_t nb = live ? block_frames(prm, blk) : 0u;
     const bool stereo = prm.channels == 2;
+    const bool est = stereo && prm.stereo_mode == 2;
+    // estimate_channel_proxy_cost: ref lac/encoder.cpp:114-124 -- sums[blk][kind * 4 + channel], kind = raw, diff, anti
+    uint64_t bits = 0;
+    if (est && live && sub < 12) bits = approx_rice_bits(sums[(size_t)blk * 12 + sub], nb);
+    auto from = [&](int lane_in_group) {
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)bits, grp + lane_in_group, 64);
+        const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(bits >> 32), grp + lane_in_group, 64);
+        return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t chbits[4];
+    bool active = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint64_t raw = from(c), dif = from(4 + c), ant = from(8 + c);
+        uint64_t mn = raw < dif ? raw : dif;
+        if (ant < mn) mn = ant;
+        chbits[c] = mn;
+        active = active || (raw < dif) || (ant < dif);
+    }
+    if (!live || sub != 0) return;
     BlockPlan bp;
     bp.choose_ms = 0;
     bp.uncertain = 0;
@@ -521,20 +546,8 @@ __global__ __launch_bounds__(64) void k_stereo(AnalyzeParams prm, const unsigned
         nfull = 0xCu;
         bp.choose_ms = 1;
     } else {
-        // estimate_channel_proxy_cost + decision: ref lac/encoder.cpp:114-124, 179-196
-        const unsigned long long* s = sums + (size_t)blk * 12;
-        uint64_t bits[4];
-        bool active = false;
-        for (int c = 0; c < 4; ++c) {
-            const uint64_t raw = approx_rice_bits(s[c], nb);
-            const uint64_t dif = approx_rice_bits(s[4 + c], nb);
-            const uint64_t ant = approx_rice_bits(s[8 + c], nb);
-            uint64_t mn = raw < dif ? raw : dif;
-            if (ant < mn) mn = ant;
-            bits[c] = mn;
-            active = active || (raw < dif) || (ant < dif);
-        }
-        const uint64_t lr = bits[0] + bits[1], ms = bits[2] + bits[3];
+        // the decision: ref lac/encoder.cpp:179-196
+        const uint64_t lr = chbits[0] + chbits[1], ms = chbits[2] + chbits[3];
         const uint64_t smaller = lr < ms ? lr : ms;
         const uint64_t diff = lr >= ms ? lr - ms : ms - lr;
         bp.est_ms = ms < lr;
@@ -1172,7 +1185,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     }
     if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &sh.plan);
     __syncthreads();
-    for (int i = tid; i < (int)(sizeof(ChannelPlan) / 4); i += G::T)
+    // only the head and the partitions in use: the rest of the record is zero already (the plans are cleared per call)
+    const int plan_words = (int)(offsetof(ChannelPlan, part_mode_k) + ((size_t)1 << sh.plan.partition_order) + 3) / 4;
+    for (int i = tid; i < plan_words; i += G::T)
         reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
     STAMP(21);
     if constexpr (G::T == 1024) {
@@ -1263,31 +1278,30 @@ __global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, Blo
                                                const uint32_t* __restrict__ need_probe,
                                                uint32_t* __restrict__ need_full,
                                                const ChannelPlan* __restrict__ plans) {
-    const uint32_t blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= prm.num_blocks) return;
-    if (prm.channels != 2 || prm.stereo_mode != 2) return;
-    BlockPlan bp = bplans[blk];
-    if (!bp.uncertain) return;
-    const ChannelPlan* p = plans + (size_t)blk * kSlotsPerBlock;
-    if (phase == 1) {
-        if (need_probe[blk] == 0) return;
-        uint64_t lr = 0, ms = 0;  // ref lac/encoder.cpp:347-353
-        for (int w = 1; w <= 3; ++w) {
-            lr += (uint64_t)p[w * 4 + CH_L].payload_bytes + p[w * 4 + CH_R].payload_bytes;
-            ms += (uint64_t)p[w * 4 + CH_M].payload_bytes + p[w * 4 + CH_S].payload_bytes;
-        }
-        bp.choose_ms = ms < lr;
-        bplans[blk] = bp;
-        need_full[blk] = bp.choose_ms ? 0xCu : 0x3u;
-    } else {
-        if (bp.frames > (uint32_t)kFullCompareLimit) return;
-        const uint64_t lr = (uint64_t)p[CH_L].payload_bytes + p[CH_R].payload_bytes;  // ref lac/encoder.cpp:337-339
-        const uint64_t ms = (uint64_t)p[CH_M].payload_bytes + p[CH_S].payload_bytes;
-        bp.choose_ms = ms < lr;
-        bplans[blk] = bp;
+    // sixteen lanes per block, lane s reads slot s's size: one round of loads instead of twelve dependent cache misses
+    const int tid = threadIdx.x, sub = tid & 15;
+    const uint32_t blk = blockIdx.x * 4u + (uint32_t)(tid >> 4);
+    if (prm.channels != 2 || prm.stereo_mode != 2) return;  // uniform
+    const bool live = blk < prm.num_blocks;
+    BlockPlan bp{};
+    if (live) bp = bplans[blk];
+    const bool mine = live && bp.uncertain &&
+                      (phase == 1 ? need_probe[blk] != 0 : bp.frames <= (uint32_t)kFullCompareLimit);
+    // phase 1: the 12 probe slots (4..15); phase 2: the whole-block slots (0..3)
+    const bool take = mine && (phase == 1 ? sub >= 4 : sub < 4);
+    const uint32_t bytes = take ? plans[(size_t)blk * kSlotsPerBlock + sub].payload_bytes : 0u;
+    const bool is_ms = (sub & 3) >= 2;  // slot = window * 4 + channel, channels L R M S
+    uint32_t lr = is_ms ? 0u : bytes, ms = is_ms ? bytes : 0u;  // sums of <= 12 sizes below 2^18: 32 bits
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        lr += (uint32_t)__shfl_xor((int)lr, d, 64);
+        ms += (uint32_t)__shfl_xor((int)ms, d, 64);
     }
+    if (!mine || sub != 0) return;
+    bp.choose_ms = ms < lr;  // ref lac/encoder.cpp:347-353 (probes), :337-339 (small block)
+    bplans[blk] = bp;
+    if (phase == 1) need_full[blk] = bp.choose_ms ? 0xCu : 0x3u;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // device-side emit: k_offsets + k_emit
@@ -1703,7 +1717,7 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, d_left, d_right, prm, ws.sums,
                        ws.badidx, ws.acorr);
-    hipLaunchKernelGGL(k_stereo, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, ws.sums, ws.badidx, ws.bplans,
+    hipLaunchKernelGGL(k_stereo, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, ws.sums, ws.badidx, ws.bplans,
                        ws.need_probe, ws.need_full);
     hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
                        sizeof(LevMem), stream, prm, ws.acorr, ws.need_probe, ws.lpcs);
@@ -1713,7 +1727,7 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
                            d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr,
                            (unsigned long long*)nullptr, FuseArgs{});
-        hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
@@ -1734,7 +1748,7 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
     if (autost && last_frames <= (uint64_t)kFullCompareLimit) {  // phase 2 only concerns such a final block
-        hipLaunchKernelGGL(k_decide, dim3((nb + 63) / 64), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[4], stream);

@@ -411,6 +411,7 @@ void add_chunk_timing(lacx_encoder* e, int c) {
     if (hipEventElapsedTime(&f, e->ev[c][0], e->ev[c][1]) == hipSuccess) e->timing.ingest_ms += f;
     if (hipEventElapsedTime(&f, e->ev[c][1], e->ev[c][2]) == hipSuccess) e->timing.probe_ms += f;
     if (hipEventElapsedTime(&f, e->ev[c][2], e->ev[c][3]) == hipSuccess) e->timing.full_ms += f;
+    (void)hipGetLastError();  // an event that was not recorded in this call must not poison the next launch check
 }
 
 void count_slots(lacx_encoder* e, uint32_t first, uint32_t count) {
@@ -958,6 +959,7 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         add_chunk_timing(e, (int)c);
         float f = 0;
         if (hipEventElapsedTime(&f, e->ev[c][4], e->ev[c][5]) == hipSuccess) e->timing.emit_ms += f;
+        (void)hipGetLastError();
     }
     e->timing.full_launches = (uint32_t)chunks.size();
     e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
