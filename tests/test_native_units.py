@@ -80,6 +80,33 @@ def test_simulated_kernel_plans_match_oracle(pkg, oracle, sim, kind):
     _check(sim, oracle, left[:16384], 0, True, False, 0)
 
 
+def test_zero_run_bound_formula_is_a_lower_bound():
+    """candidate_lower_bound()'s zero term, min(3 Z, 3 (R - 1) + 4 + (Z - R + 1) / 4) for Z zeros in at least R runs, against
+    the exact minimum over every way of cutting Z zeros into R' >= R runs (a run of L costs 3 L below 4 and 4 + L / 4 from
+    4 on: ref block/encoder.cpp:224-247 with the cheapest Rice parameter)."""
+    import functools
+
+    def run_cost(length):
+        return 3 * length if length < 4 else 4 + length // 4
+
+    @functools.lru_cache(None)
+    def cheapest(zeros, runs):
+        if runs == 1:
+            return run_cost(zeros) if zeros >= 1 else 10**9
+        return min(run_cost(first) + cheapest(zeros - first, runs - 1) for first in range(1, zeros - runs + 2))
+
+    def bound(zeros, ends):
+        if zeros == 0:
+            return 0
+        runs = max(ends, 1)
+        return min(3 * zeros, 3 * (runs - 1) + 4 + ((zeros - runs + 1) >> 2))
+
+    for zeros in range(1, 48):
+        for ends in range(0, zeros + 1):
+            assert bound(zeros, ends) <= min(cheapest(zeros, r) for r in range(max(ends, 1), zeros + 1)), (zeros, ends)
+    assert bound(16384, 1) == run_cost(16384)  # an all-zero block meets the bound
+
+
 def test_pruning_bound_on_zero_run_structures(pkg, oracle, sim):
     """The candidate pruning bound's zero-run term (zeros cost at least min(3 Z, 3 (R - 1) + 4 + (Z - R + 1) / 4) bits for
     Z zeros in at least R runs): all-zero blocks, isolated non-zeros, periodic patterns and randomly punched gaps of
