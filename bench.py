@@ -442,8 +442,8 @@ def worker(args) -> int:
         same = (view.tobytes() == gpu_lac) if gpu_lac is not None else None
         e2e = {"value": round(frames * 2 / (best / 1e3) / 1e6, 3), "unit": "Msamples/s", "ms": round(best, 3),
                "ms_python_wall": round(min(wall_ms), 3), "h2d_host_ms": round(min(h2d), 3),
-               "path": "WAV image in pageable host memory -> lacx_encode_wav_view (RIFF walk, upload pipelined with the analysis in 4 "
-                       "chunks, kernels, header + table written in place) -> complete .lac in pinned host memory; ms = the library "
+               "path": "WAV image in pageable host memory -> lacx_encode_wav_view (RIFF walk, upload pipelined with the analysis in 3 "
+                       "chunks of 1:3:4, kernels, header + table written in place) -> complete .lac in pinned host memory; ms = the library "
                        "call's own wall clock",
                "byte_identical": same}
         if same is False:

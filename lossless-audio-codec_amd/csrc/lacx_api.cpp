@@ -357,8 +357,10 @@ std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused
     // 2 h shard).  With the fused emit + streaming packer nothing is left to overlap by chunking -- the payload leaves
     // while the analysis runs, and ingest / probes keep every CU busy by themselves -- and one launch set measured best
     // from 10 min to 2 h of audio (a chunked run only adds kernel boundaries).
-    // With the input still in host memory the chunks pipeline the upload: 4 chunks (one quarter of the H2D copy exposed).
-    const uint32_t dev_chunks = fused ? (upload ? 4u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
+    // With the input still in host memory the chunks pipeline the upload: three chunks of relative size 1 : 3 : 4 -- a
+    // small first one, so that little of the H2D copy is exposed before the first kernel (measured, 10 min stream, WAV
+    // image -> .lac: 4 equal chunks 4.36 ms, 1:2:3:3 4.17, 1:2:3 4.17, 1:3:4 4.11, 2:3:4 4.21, 6 or 8 equal 4.6).
+    const uint32_t dev_chunks = fused ? (upload ? 3u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
     nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
     if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
@@ -372,7 +374,7 @@ std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused
     const char* split_env = std::getenv("LACX_PIPE_SPLIT");  // tuning knob: relative chunk sizes, e.g. "5,3,1"
     // Device emit: three chunks on three streams of falling priority, the last one a little smaller -- its
     // emit is the only one whose PCIe writes are not hidden under another chunk's analysis (measured best).
-    if (!split_env && !forced && device_emit && nchunks == 3u) split_env = "5,5,4";
+    if (!split_env && !forced && device_emit && nchunks == 3u) split_env = (fused && upload) ? "1,3,4" : "5,5,4";
     if (const char* env = split_env) {
         std::vector<double> w;
         double sum = 0;
