@@ -531,7 +531,8 @@ def test_host_emit_waits_for_the_callers_stream(gpu, oracle):
         del junk
 
 
-@pytest.mark.parametrize("mode", ["fused", "k_emit_only", "every_fifth_left_to_k_emit", "packer_gives_up"])
+@pytest.mark.parametrize("mode", ["fused", "k_emit_only", "every_fifth_left_to_k_emit", "packer_gives_up",
+                                  "packer_16_waves", "packer_48_waves"])
 def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
     """The emit fused into the analysis kernel + the streaming packer beside it (default), k_offsets + k_emit alone,
     and the two repair paths: a test hook leaves every fifth channel block to k_emit, another one fills the staging
@@ -542,6 +543,10 @@ def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
         monkeypatch.setenv("LACX_DEBUG_SKIP", "1024")
     if mode == "packer_gives_up":
         monkeypatch.setenv("LACX_DEBUG_SKIP", "8192")
+    if mode == "packer_16_waves":  # the packer's waves are independent: any number of them gives the same bytes
+        monkeypatch.setenv("LACX_PACK_GRID", "1")
+    if mode == "packer_48_waves":
+        monkeypatch.setenv("LACX_PACK_GRID", "3")
     cases = [(16384 * 40 + 321, 2, 16, 48000, 2, "mixed"), (16384 * 9 + 4000, 2, 24, 96000, 2, "mixed"),
              (16384 * 7 + 5, 1, 16, 44100, 0, "music"), (16384 * 6, 2, 16, 48000, 1, "music"),
              (16384 * 5 + 77, 2, 24, 48000, 0, "noise"), (16384 * 400 + 9, 2, 16, 48000, 2, "music")]
@@ -551,7 +556,7 @@ def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
         want = oracle.encode(left, right, sr, bd, sm, threads=8)
         for _ in range(2):
             assert enc.encode(left, right) == want, (mode, frames, ch, bd)
-        if mode == "fused":
+        if mode in ("fused", "packer_16_waves", "packer_48_waves"):
             t = enc.timing()
             small_last = ch == 2 and sm == 2 and (frames % 16384) and (frames % 16384) <= 4096
             assert t.emit_direct == (-(-frames // 16384) - (1 if small_last else 0)) * ch
