@@ -11,10 +11,13 @@
 //   k_decide(1) probes -> LR/MS choice, marks the two whole-block slots still to be analysed
 //   k_analyze<16,1024>  one 1024-thread workgroup per needed whole-block slot
 //                                                           (ref block/encoder.cpp:313-552)
-//   k_decide(2) small-block full comparison (ref lac/encoder.cpp:336-340), final BlockPlan
+//                       + the bit emit of its channel block into a staging slot (ref block/encoder.cpp:554-838)
+//   k_stream_out        beside it, on its own stream: 32 packer waves move the slots to the (pinned host) payload
+//   k_decide(2) small-block full comparison (ref lac/encoder.cpp:336-340), final BlockPlan (only for such a block)
 //   k_offsets   one workgroup: block byte sizes -> payload offsets + the container's block table
-//   k_emit<16,1024>     one workgroup per chosen channel block: the bitstream, written straight into the
-//                       (pinned host) result buffer                 (ref block/encoder.cpp:554-838)
+//   k_pack, k_emit<16,1024>   repair paths: slots the packer did not move / channel blocks the fused emit left out
+//                       (k_emit alone is the whole emit with LACX_FUSED_EMIT=0)
+//   k_gather    block plans, block table, totals and flags into pinned host memory
 // The host emit (emit.cpp, LACX_FLAG_HOST_EMIT) consumes the same ChannelPlan records instead of k_offsets/k_emit.
 #include <hip/hip_runtime.h>
 
@@ -1462,7 +1465,7 @@ __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, u
 // because of where they run: an analysis workgroup fills the register files of its CU, so a packer workgroup takes a
 // whole CU away from the analysis however small it is -- sixteen packer waves on one CU cost the analysis one CU, eight
 // 256-thread workgroups cost it eight.  One CU moves about 16 GB/s into pinned host memory however many stores it keeps
-// in flight, so the 10 min stream's 57 MB in 2.5 ms need two.  Measured (ms per step: 16/48 music, 16/48 mixed,
+// in flight, so the 10 min stream's 72.6 MB in 2.5 ms need two.  Measured (ms per step: 16/48 music, 16/48 mixed,
 // 24/96 mixed): 8 x 256 threads 3.15 / 4.15 / 8.33; 1 x 1024 4.02 (packer too slow) / 3.99 / -; 2 x 1024 3.12 / 4.02 /
 // 8.15; 3 x 1024 3.27 / 3.98 / 8.22; 4 x 1024 3.29 / 3.96 / 8.17.  total: fusable stream indices of the shard.
 #ifndef LACX_STREAM_UNROLL
