@@ -62,6 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-weak-line", action="store_true", help="N>1: skip the additional 10 min per GPU measurement")
     ap.add_argument("--no-end-to-end", action="store_true", help="N=1: skip the host WAV -> host .lac measurement")
+    ap.add_argument("--no-decode-check", action="store_true", help="N=1: skip decoding the GPU's .lac on the device")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
     ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
@@ -449,6 +450,21 @@ def worker(args) -> int:
         if same is False:
             raise SystemExit("bench.py: lacx_encode_wav_view output differs from the device-resident encode")
 
+    decode_check = None
+    if world == 1 and gpu_lac is not None and not args.no_decode_check:
+        # The product's own decoder (lacx_decode, one lane per block on the device) on the last timed step's .lac: the PCM
+        # must come back sample for sample.  No oracle involved; outside every timed region.
+        t1 = time.perf_counter()
+        dl, dr, dinfo, dec_ms = pkg.lacx.decode(gpu_lac)
+        wall = (time.perf_counter() - t1) * 1e3
+        same_pcm = bool(np.array_equal(dl, left) and np.array_equal(dr, right))
+        decode_check = {"pcm_identical": same_pcm, "kernel_ms": round(dec_ms, 3), "wall_ms_incl_copies": round(wall, 1),
+                        "value": round(frames * 2 / (dec_ms / 1e3) / 1e6, 1) if dec_ms > 0 else None, "unit": "Msamples/s",
+                        "blocks": int(dinfo.blocks)}
+        del dl, dr
+        if not same_pcm:
+            raise SystemExit("bench.py: the GPU .lac does not decode back to the PCM -- refusing to report a number")
+
     out = {
         "metric": METRIC,
         "value": round(main["value"], 3),
@@ -495,6 +511,7 @@ def worker(args) -> int:
         "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_all,
         "end_to_end": e2e,
+        "decode_check": decode_check,
         "byte_identical_to_cpu_baseline": identical,
         "matches_golden_digest": digest_ok,
     }

@@ -190,13 +190,35 @@ int lacx_wav_parse(const uint8_t* wav, uint64_t size, lacx_wav_info* out);
 int lacx_encode_wav(lacx_encoder* enc, const uint8_t* wav, uint64_t size, uint8_t** out, uint64_t* out_size);
 /* Zero-copy variant: *out points at the complete .lac inside the encoder's pinned result buffer (the device wrote the
  * payload there, header and block table are filled in in front of it); valid until the next call on the same encoder.
- * The upload is pipelined: the data chunk goes to the device in four pieces, each in front of its kernels. */
+ * The upload is pipelined: the data chunk goes to the device in three pieces (1 : 3 : 4), each in front of its kernels. */
 int lacx_encode_wav_view(lacx_encoder* enc, const uint8_t* wav, uint64_t size, const uint8_t** out, uint64_t* out_size);
 
 /* Host-only: header + block table + payload concat of shards given in stream order. */
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
                   const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,
                   uint8_t** out, uint64_t* out_size);
+
+/* ---- decode: LAC::Decoder::decode, ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
+ * src/codec/block/decoder.cpp:64-520.  The product's own check that a .lac gives back the PCM, on the device: one lane
+ * per block (the format serialises everything inside a block), all blocks of the stream at once.
+ * lacx_stream_parse: host only; header + block table consistency (LACX_E_INVALID otherwise).
+ * lacx_decode: left / right (right may be null for mono) are caller-owned arrays of `frames` int32 each; a malformed
+ * block, a sample outside the bit depth or a residual magnitude the encoder's domain cannot produce (>= 2^30) gives
+ * LACX_E_RUNTIME ("[decode-error] block=N ..." in lacx_decode_last_error, the reference throws std::runtime_error with
+ * that prefix, decoder.cpp:24-32).  device = -1: the current device.  device_ms (nullable): kernel time. */
+typedef struct lacx_stream_info {
+    uint32_t sample_rate;
+    uint32_t blocks;
+    uint64_t frames;
+    uint8_t channels;
+    uint8_t bit_depth;
+    uint8_t stereo_mode;
+    uint8_t reserved;
+} lacx_stream_info;
+int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out);
+int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
+                float* device_ms);
+const char* lacx_decode_last_error(void); /* of the calling thread */
 
 /* Block::Encoder::encode drop-in for one channel block of n <= 16384 samples, |x| <= 2^24. */
 int lacx_block_encode(lacx_encoder* enc, const int32_t* pcm, uint32_t n, uint8_t** out, uint64_t* out_size);

@@ -1,0 +1,390 @@
+// decode.hip -- CDNA4 (gfx950) kernels of the LAC v3 decoder (the product's own check that a .lac it
+// produced gives back the PCM, on a box where the reference is absent).
+//
+// What the format allows to run in parallel is the block: inside a block the two channel bitstreams follow each other
+// byte-aligned but without a length field, every token's length depends on the Rice parameter, and the Rice parameter
+// depends on every sample decoded before it (ref src/codec/block/decoder.cpp:64-520, src/codec/rice/rice.hpp:45-114).
+// So: ONE LANE PER BLOCK, both channels one after the other, all blocks of the stream at once -- the duration is one
+// block's serial chain whatever the stream's length (up to the chip's ~65 000 resident lanes = 18 h of audio), and the
+// throughput comes from the number of blocks.  Per-lane state that must be indexed lives in LDS, one column per lane:
+// the last 256 residual magnitudes of the stateful Rice adaptation and the predictor's history.
+//   k_decode      bitstream -> residuals -> samples (fixed / FIR / LPC synthesis), planar int32, per-block status
+//   k_ms_inverse  mid/side -> left/right where the block's flag says so, and the bit-depth range check
+//                                                                        (ref src/codec/lac/decoder.cpp:48-65,30-46)
+// The adaptive Rice parameter uses the encoder's division-free formulation (kmean / biased_k of analyze_core.h, proven
+// against Rice::adapt_k there); it assumes zigzag residuals below 2^30 like the encoder does, and a stream with a larger
+// one is refused (status 9) rather than decoded differently from the reference.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "analyze_core.h"
+#include "kernels.h"
+
+namespace lacx {
+
+namespace {
+
+constexpr int kDecThreads = 64;
+constexpr uint32_t kModeRice = 0, kModeBin = 2, kModeStatic = 3;  // (1 = zero-run)  ref block/constants.hpp
+constexpr uint32_t kZeroRunMin = 4, kZeroRunK = 2;
+
+struct DecMem {  // one column per lane
+    uint32_t ring[256][kDecThreads];  // the last 256 residual magnitudes (stateful adaptation's drift window)
+    int32_t hist[32][kDecThreads];    // the last 32 reconstructed samples (LPC orders up to 32 are valid streams)
+    int16_t coef[32][kDecThreads];    // the channel block's Q15 coefficients
+};
+
+// MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  The buffer is padded
+// with 16 zero bytes, so that a window fetched at the very end stays inside it; reading past nbits sets err.
+struct BitIn {
+    const uint8_t* p;
+    unsigned long long nbits, pos;
+    uint32_t err;
+};
+
+__device__ __forceinline__ unsigned long long window(const BitIn& r) {  // >= 57 valid bits from r.pos on, left-aligned
+    const unsigned long long byte = r.pos >> 3;
+    unsigned long long w;
+    __builtin_memcpy(&w, r.p + byte, 8);
+    w = __builtin_bswap64(w);
+    return w << (r.pos & 7u);
+}
+__device__ __forceinline__ uint32_t get_bits(BitIn& r, uint32_t n) {  // n <= 32
+    if (n == 0) return 0;
+    if (r.pos + n > r.nbits) {
+        r.err = 1;
+        return 0;
+    }
+    const uint32_t v = (uint32_t)(window(r) >> (64u - n));
+    r.pos += n;
+    return v;
+}
+// unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86)
+__device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q) {
+    unsigned long long c = 0;
+    for (;;) {
+        if (r.pos >= r.nbits) {
+            r.err = 1;
+            return false;
+        }
+        const unsigned long long w = window(r) | 0x7Full;  // the low 7 bits are not valid: make them ones
+        uint32_t ones = (uint32_t)__clzll((long long)~w);  // 0..57 leading ones among the valid bits
+        const unsigned long long left = r.nbits - r.pos;
+        if (ones > 57u) ones = 57u;
+        if ((unsigned long long)ones >= left) {  // ran into the end without a terminator
+            r.err = 1;
+            return false;
+        }
+        if (ones < 57u) {
+            c += ones;
+            r.pos += ones + 1u;
+            break;
+        }
+        c += 57u;
+        r.pos += 57u;
+        if (c > (unsigned long long)max_q) return false;
+    }
+    if (c > (unsigned long long)max_q) return false;
+    q = (uint32_t)c;
+    return true;
+}
+__device__ __forceinline__ bool get_rice(BitIn& r, uint32_t k, uint32_t& value) {
+    if (k > 31u) return false;
+    uint32_t q = 0;
+    if (!get_unary(r, 0xFFFFFFFFu >> k, q)) return false;
+    const uint32_t rem = get_bits(r, k);
+    if (r.err) return false;
+    value = (q << k) | rem;
+    return true;
+}
+__device__ __forceinline__ int32_t unzigzag(uint32_t u) {
+    return (u & 1u) ? (int32_t)(-(long long)((u >> 1) + 1u)) : (int32_t)(u >> 1);
+}
+__device__ __forceinline__ uint32_t zigzag(int32_t v) { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); }
+
+// Rice::AdaptState in the encoder's feed-forward form: prefix sum, count, the sum of the last 256 magnitudes (ring in
+// LDS) and the two flag counts over the last 96 samples (flags in two 96-bit shift registers).
+struct Adapt {
+    unsigned long long sum, wsum;
+    uint32_t count, large, zero;
+    uint32_t lf[3], zf[3];
+};
+__device__ __forceinline__ void adapt_reset(Adapt& a) {
+    a.sum = a.wsum = 0;
+    a.count = a.large = a.zero = 0;
+    a.lf[0] = a.lf[1] = a.lf[2] = a.zf[0] = a.zf[1] = a.zf[2] = 0;
+}
+// one more sample of magnitude u; returns the parameter for the next one (ref rice.hpp:45-114 / encoder.cpp:72-77)
+__device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool stateless, DecMem& dm, int lane) {
+    a.sum += u;
+    ++a.count;
+    const uint32_t km = kmean(a.sum, a.count);
+    if (stateless) return km > 31u ? 31u : km;
+    // drift window: the last 256 magnitudes
+    const uint32_t slot = (a.count - 1u) & 255u;
+    if (a.count > 256u) a.wsum -= dm.ring[slot][lane];
+    dm.ring[slot][lane] = u;
+    a.wsum += u;
+    // micro window: flags of the last 96 samples
+    const uint32_t q = km >= 31u ? 0u : (u >> km);
+    const uint32_t fl = q > 3u ? 1u : 0u, fz = q == 0u ? 1u : 0u;
+    a.large += fl - (a.lf[2] >> 31);
+    a.zero += fz - (a.zf[2] >> 31);
+    a.lf[2] = (a.lf[2] << 1) | (a.lf[1] >> 31);
+    a.lf[1] = (a.lf[1] << 1) | (a.lf[0] >> 31);
+    a.lf[0] = (a.lf[0] << 1) | fl;
+    a.zf[2] = (a.zf[2] << 1) | (a.zf[1] >> 31);
+    a.zf[1] = (a.zf[1] << 1) | (a.zf[0] >> 31);
+    a.zf[0] = (a.zf[0] << 1) | fz;
+    return biased_k<false>(km, a.sum, a.sum - a.wsum, a.large | (a.zero << 16), a.count);
+}
+
+// One partition (ref block/decoder.cpp:88-330).  Residuals go to out[0..samples); 0 = ok, else a status code.
+__device__ uint32_t decode_segment(BitIn& r, uint32_t samples, uint32_t k0, uint32_t mode, int32_t* __restrict__ out,
+                                   bool stateless, DecMem& dm, int lane) {
+    Adapt a;
+    adapt_reset(a);
+    uint32_t k = k0;
+    if (mode == kModeStatic) {
+        for (uint32_t i = 0; i < samples; ++i) {
+            uint32_t u;
+            if (!get_rice(r, k0, u)) return 3;
+            if (u >> 30) return 9;
+            out[i] = unzigzag(u);
+        }
+        return 0;
+    }
+    if (mode == kModeRice) {
+        for (uint32_t i = 0; i < samples; ++i) {
+            uint32_t u;
+            if (!get_rice(r, k, u)) return 3;
+            if (u >> 30) return 9;
+            out[i] = unzigzag(u);
+            k = adapt_next(a, u, stateless, dm, lane);
+        }
+        return 0;
+    }
+    if (mode == kModeBin) {
+        for (uint32_t i = 0; i < samples; ++i) {
+            const uint32_t tag = get_bits(r, 2);
+            if (r.err) return 3;
+            uint32_t u = 0;
+            if (tag == 1u || tag == 2u) {
+                const uint32_t sgn = get_bits(r, 1);
+                if (r.err) return 3;
+                u = zigzag(sgn ? -(int32_t)tag : (int32_t)tag);
+            } else if (tag == 3u) {
+                if (!get_rice(r, k, u)) return 3;
+                if (u >> 30) return 9;
+            }
+            out[i] = unzigzag(u);
+            k = adapt_next(a, u, stateless, dm, lane);
+        }
+        return 0;
+    }
+    // zero-run mode
+    uint32_t idx = 0;
+    while (idx < samples) {
+        const uint32_t tag = get_bits(r, 2);
+        if (r.err || tag > 2u) return 3;
+        if (tag == 1u) {
+            uint32_t enc;
+            if (!get_rice(r, kZeroRunK, enc)) return 3;
+            const unsigned long long run = (unsigned long long)enc + kZeroRunMin;
+            if (run > (unsigned long long)(samples - idx)) return 3;
+            for (uint32_t j = 0; j < (uint32_t)run; ++j) out[idx + j] = 0;
+            idx += (uint32_t)run;
+            if (stateless) {  // the count jumps, the parameter is recomputed once (ref block/decoder.cpp zero-run branch)
+                a.count += (uint32_t)run;
+                const uint32_t km = kmean(a.sum, a.count);
+                k = km > 31u ? 31u : km;
+            } else {
+                for (uint32_t j = 0; j < (uint32_t)run; ++j) k = adapt_next(a, 0u, false, dm, lane);
+            }
+        } else {
+            uint32_t u;
+            if (tag == 0u) {
+                if (!get_rice(r, k, u)) return 3;
+            } else {
+                u = get_bits(r, 32);  // escape: the zigzag value verbatim
+                if (r.err) return 3;
+                u = zigzag(unzigzag(u));
+            }
+            if (u >> 30) return 9;
+            out[idx++] = unzigzag(u);
+            k = adapt_next(a, u, stateless, dm, lane);
+        }
+    }
+    return 0;
+}
+
+// One channel block: header, partition table, residual, zero padding to the byte, synthesis in place
+// (ref block/decoder.cpp:64-520).
+__device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restrict__ out, DecMem& dm, int lane) {
+    const uint32_t type = get_bits(r, 8);
+    const int order = (int)get_bits(r, 8);
+    if (r.err || type > 2u) return 2;
+    if (type == 2u) {
+        if (order <= 0 || order > 32 || (uint32_t)order >= n) return 2;
+    } else if (type == 1u) {
+        if (order != 2) return 2;
+    } else if (order > 4) {
+        return 2;
+    }
+    if (type == 2u) {
+        for (int i = 0; i < order; ++i) dm.coef[i][lane] = (int16_t)get_bits(r, 16);
+        if (r.err) return 2;
+    }
+    const uint32_t control = get_bits(r, 8);
+    if (r.err || (control & 0x10u)) return 2;
+    const bool pflag = (control & 0x80u) != 0u;
+    const uint32_t p = control & 0x0Fu, cmode = (control >> 5) & 3u;
+    if ((pflag && p == 0u) || (!pflag && p != 0u) || p > (uint32_t)kMaxPartitionOrder) return 2;
+    if (p > 0u && (n >> p) < (uint32_t)kMinPartition) return 2;
+    const uint32_t parts = (p == 0u || (n >> p) == 0u) ? 1u : (1u << p);
+    const uint32_t base = parts == 1u ? n : (n >> p);
+    const unsigned long long table_pos = r.pos;  // (mode:2, k:5) per partition, read again partition by partition
+    if (r.pos + 7ull * parts > r.nbits) return 2;
+    r.pos += 7ull * parts;
+    uint32_t off = 0;
+    for (uint32_t i = 0; i < parts; ++i) {
+        BitIn t = r;
+        t.pos = table_pos + 7ull * i;
+        const uint32_t mode = get_bits(t, 2), k0 = get_bits(t, 5);
+        if (i == 0u && mode != cmode) return 2;
+        const uint32_t len = (i + 1u == parts) ? n - base * (parts - 1u) : base;
+        const uint32_t st = decode_segment(r, len, k0, mode, out + off, p > 0u, dm, lane);
+        if (st) return st;
+        off += len;
+    }
+    while (r.pos & 7u) {  // zero padding to the byte (ref bit_reader.hpp consume_zero_padding_to_byte)
+        if (get_bits(r, 1) || r.err) return 4;
+    }
+    // synthesis in place; the history of the last `order` samples rides in the lane's LDS column
+    if (type == 0u) {
+        long long h1 = 0, h2 = 0, h3 = 0, h4 = 0;  // out[i-1..i-4]
+        for (uint32_t i = 0; i < n; ++i) {
+            long long s = out[i];
+            if (i >= (uint32_t)order) {
+                long long pred = 0;
+                switch (order) {
+                    case 1: pred = h1; break;
+                    case 2: pred = 2 * h1 - h2; break;
+                    case 3: pred = 3 * h1 - 3 * h2 + h3; break;
+                    case 4: pred = 4 * h1 - 6 * h2 + 4 * h3 - h4; break;
+                    default: break;
+                }
+                s += pred;
+                if (s < -2147483648ll || s > 2147483647ll) return 5;
+                out[i] = (int32_t)s;
+            }
+            h4 = h3;
+            h3 = h2;
+            h2 = h1;
+            h1 = s;
+        }
+    } else if (type == 1u) {
+        long long h1 = 0, h2 = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            long long s = out[i];
+            if (i >= 2u) {
+                s += (3 * h1 - h2) >> 2;
+                if (s < -2147483648ll || s > 2147483647ll) return 5;
+                out[i] = (int32_t)s;
+            }
+            h2 = h1;
+            h1 = s;
+        }
+    } else {
+        for (uint32_t i = 0; i < n; ++i) {
+            long long acc = 0;
+            const int taps = order < (int)i ? order : (int)i;
+            for (int t = 1; t <= taps; ++t)
+                acc += (long long)dm.coef[t - 1][lane] * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
+            const long long s = (acc >> 15) + (long long)out[i];
+            if (s < -2147483648ll || s > 2147483647ll) return 5;
+            out[i] = (int32_t)s;
+            dm.hist[i & 31u][lane] = (int32_t)s;
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kDecThreads) void k_decode(uint32_t num_blocks, int channels, int stereo_mode,
+                                                        const uint8_t* __restrict__ payload,
+                                                        const unsigned long long* __restrict__ byte_off,
+                                                        const unsigned long long* __restrict__ frame_off,
+                                                        int32_t* __restrict__ left, int32_t* __restrict__ right,
+                                                        uint32_t* __restrict__ status, uint8_t* __restrict__ ms_flag) {
+    extern __shared__ __align__(16) unsigned char dec_raw[];
+    DecMem& dm = *reinterpret_cast<DecMem*>(dec_raw);
+    const int lane = (int)threadIdx.x;
+    const uint32_t blk = blockIdx.x * (uint32_t)kDecThreads + threadIdx.x;
+    if (blk >= num_blocks) return;
+    const uint32_t n = (uint32_t)(frame_off[blk + 1] - frame_off[blk]);
+    BitIn r;
+    r.p = payload + byte_off[blk];
+    r.nbits = 8ull * (byte_off[blk + 1] - byte_off[blk]);
+    r.pos = 0;
+    r.err = 0;
+    uint32_t st = 0;
+    uint32_t ms = stereo_mode == 1 ? 1u : 0u;
+    if (n == 0u || n > (uint32_t)kMaxBlock) st = 1;
+    if (!st && channels == 2 && stereo_mode == 2) {  // per-block flag byte (ref lac/decoder.cpp)
+        const uint32_t flag = get_bits(r, 8);
+        if (r.err || flag > 1u) st = 1;
+        ms = flag;
+    }
+    if (!st) st = decode_channel_block(r, n, left + frame_off[blk], dm, lane);
+    if (!st && channels == 2) st = decode_channel_block(r, n, right + frame_off[blk], dm, lane);
+    if (!st && r.pos != r.nbits) st = 6;  // trailing bytes in the block
+    status[blk] = st;
+    ms_flag[blk] = (uint8_t)ms;
+}
+
+// grid = (blocks, tiles): the samples of block blockIdx.x in tiles of 1024
+__global__ __launch_bounds__(256) void k_ms_inverse(int channels, int bit_depth,
+                                                    const unsigned long long* __restrict__ frame_off,
+                                                    int32_t* __restrict__ left, int32_t* __restrict__ right,
+                                                    const uint8_t* __restrict__ ms_flag, uint32_t* __restrict__ status) {
+    const uint32_t blk = blockIdx.x, tile = blockIdx.y;
+    if (status[blk]) return;  // (uniform) the block did not decode
+    const unsigned long long f0 = frame_off[blk];
+    const uint32_t n = (uint32_t)(frame_off[blk + 1] - f0);
+    const bool ms = channels == 2 && ms_flag[blk] != 0;
+    const long long lo = bit_depth == 16 ? -32768 : -0x800000, hi = bit_depth == 16 ? 32767 : 0x7FFFFF;
+    bool bad = false;
+    for (uint32_t i = tile * 1024u + threadIdx.x; i < n && i < (tile + 1u) * 1024u; i += 256u) {
+        long long l = left[f0 + i], rr = channels == 2 ? right[f0 + i] : 0;
+        if (ms) {  // ref lac/decoder.cpp:48-65
+            const long long m = l, s = rr;
+            l = m + ((s + (s & 1)) >> 1);
+            rr = l - s;
+            left[f0 + i] = (int32_t)l;
+            right[f0 + i] = (int32_t)rr;
+        }
+        bad = bad || l < lo || l > hi || (channels == 2 && (rr < lo || rr > hi));
+    }
+    if (bad) atomicMax(&status[blk], 7u);
+}
+
+size_t decode_smem_bytes() { return sizeof(DecMem); }
+
+hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
+                         const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,
+                         int32_t* right, uint32_t* status, uint8_t* ms_flag, hipStream_t stream) {
+    if (num_blocks == 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(DecMem));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_decode, dim3((num_blocks + kDecThreads - 1) / kDecThreads), dim3(kDecThreads), sizeof(DecMem), stream,
+                       num_blocks, channels, stereo_mode, payload, byte_off, frame_off, left, right, status, ms_flag);
+    hipLaunchKernelGGL(k_ms_inverse, dim3(num_blocks, kMaxBlock / 1024), dim3(256), 0, stream, channels, bit_depth, frame_off,
+                       left, right, (const uint8_t*)ms_flag, status);
+    return hipGetLastError();
+}
+
+}  // namespace lacx

@@ -1513,6 +1513,125 @@ int lacx_encode_wav(lacx_encoder* e, const uint8_t* wav, uint64_t size, uint8_t*
     return LACX_OK;
 }
 
+// ---- decode -------------------------------------------------------------------------------------
+namespace {
+thread_local std::string g_decode_err;
+int decode_fail(int code, const std::string& msg) {
+    g_decode_err = msg;
+    return code;
+}
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+}  // namespace
+
+const char* lacx_decode_last_error(void) { return g_decode_err.c_str(); }
+
+// Container header + block table (ref src/codec/frame/frame_header.hpp:25-60, lac/decoder.cpp:90-200): magic, version 3,
+// channels, stereo mode, rate, depth, reserved byte, block count, (frames, bytes) per block; the sizes must add up.
+int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out) {
+    if (!lac || !out) return decode_fail(LACX_E_INVALID, "null argument");
+    if (size < 14 || lac[0] != 0x4C || lac[1] != 0x41 || lac[2] != 3) return decode_fail(LACX_E_INVALID, "[decode-error] bad header");
+    const int ch = lac[3], sm = lac[4], bd = lac[8];
+    const uint32_t sr = ((uint32_t)lac[5] << 8) | lac[6] | ((uint32_t)lac[7] << 16);
+    if ((ch != 1 && ch != 2) || sm > 2 || (bd != 16 && bd != 24) || lac[9] != 0)
+        return decode_fail(LACX_E_INVALID, "[decode-error] bad header");
+    const uint32_t nb = be32(lac + 10);
+    if (size < 14 + 8ull * nb) return decode_fail(LACX_E_INVALID, "[decode-error] truncated block table");
+    uint64_t frames = 0, pay = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t n = be32(lac + 14 + 8ull * b), by = be32(lac + 18 + 8ull * b);
+        if (n == 0 || n > (uint32_t)kMaxBlock || by == 0) return decode_fail(LACX_E_INVALID, "[decode-error] bad block table entry");
+        frames += n;
+        pay += by;
+    }
+    if (14 + 8ull * nb + pay != size) return decode_fail(LACX_E_INVALID, "[decode-error] sizes do not add up");
+    out->sample_rate = sr;
+    out->blocks = nb;
+    out->frames = frames;
+    out->channels = (uint8_t)ch;
+    out->bit_depth = (uint8_t)bd;
+    out->stereo_mode = (uint8_t)sm;
+    out->reserved = 0;
+    return LACX_OK;
+}
+
+int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
+                float* device_ms) {
+    lacx_stream_info info;
+    const int prc = lacx_stream_parse(lac, size, &info);
+    if (prc) return prc;
+    if (!left || (info.channels == 2 && !right)) return decode_fail(LACX_E_INVALID, "output arrays missing");
+    if (frames != info.frames) return decode_fail(LACX_E_INVALID, "output arrays do not match the stream's frame count");
+    if (device_ms) *device_ms = 0.f;
+    if (info.blocks == 0) return LACX_OK;
+    if (lacx_device_count() <= 0) return decode_fail(LACX_E_DEVICE, "no usable HIP device");
+#define DEC_TRY(call, what)                                                                                  \
+    do {                                                                                                     \
+        const hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) {                                                                              \
+            rc = decode_fail(LACX_E_DEVICE, std::string(what) + ": " + hipGetErrorString(_e));               \
+            goto done;                                                                                       \
+        }                                                                                                    \
+    } while (0)
+    int rc = LACX_OK;
+    const uint32_t nb = info.blocks;
+    const uint64_t head = 14 + 8ull * nb, pay = size - head;
+    std::vector<unsigned long long> offs(2 * ((size_t)nb + 1));  // byte offsets, then frame offsets
+    unsigned long long* byte_off = offs.data();
+    unsigned long long* frame_off = offs.data() + nb + 1;
+    byte_off[0] = frame_off[0] = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        frame_off[b + 1] = frame_off[b] + be32(lac + 14 + 8ull * b);
+        byte_off[b + 1] = byte_off[b] + be32(lac + 18 + 8ull * b);
+    }
+    uint8_t* d_pay = nullptr;
+    unsigned long long* d_offs = nullptr;
+    int32_t *d_left = nullptr, *d_right = nullptr;
+    uint32_t* d_status = nullptr;
+    uint8_t* d_ms = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<uint32_t> status(nb);
+    if (device >= 0) DEC_TRY(hipSetDevice(device), "hipSetDevice");
+    DEC_TRY(hipMalloc((void**)&d_pay, pay + 16), "hipMalloc(payload)");
+    DEC_TRY(hipMemset(d_pay + pay, 0, 16), "memset");
+    DEC_TRY(hipMemcpy(d_pay, lac + head, pay, hipMemcpyHostToDevice), "H2D payload");
+    DEC_TRY(hipMalloc((void**)&d_offs, offs.size() * sizeof(unsigned long long)), "hipMalloc(offsets)");
+    DEC_TRY(hipMemcpy(d_offs, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "H2D offsets");
+    DEC_TRY(hipMalloc((void**)&d_left, frames * sizeof(int32_t)), "hipMalloc(left)");
+    if (info.channels == 2) DEC_TRY(hipMalloc((void**)&d_right, frames * sizeof(int32_t)), "hipMalloc(right)");
+    DEC_TRY(hipMalloc((void**)&d_status, (size_t)nb * sizeof(uint32_t)), "hipMalloc(status)");
+    DEC_TRY(hipMalloc((void**)&d_ms, nb), "hipMalloc(flags)");
+    DEC_TRY(hipEventCreate(&e0), "hipEventCreate");
+    DEC_TRY(hipEventCreate(&e1), "hipEventCreate");
+    DEC_TRY(hipEventRecord(e0, nullptr), "event record");
+    DEC_TRY(launch_decode(nb, info.channels, info.stereo_mode, info.bit_depth, d_pay, d_offs, d_offs + nb + 1, d_left, d_right,
+                          d_status, d_ms, nullptr), "decode launch");
+    DEC_TRY(hipEventRecord(e1, nullptr), "event record");
+    DEC_TRY(hipMemcpy(status.data(), d_status, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H status");
+    if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (status[b]) {  // the first failing block, like the reference's message (lac/decoder.cpp:24-32)
+            static const char* const kWhat[] = {"", "block header", "channel header", "residual", "padding", "sample overflow",
+                                                "trailing bytes", "sample outside the bit depth", "", "residual beyond 2^30"};
+            rc = decode_fail(LACX_E_RUNTIME, "[decode-error] block=" + std::to_string(b) + " " +
+                                                 (status[b] < 10 ? kWhat[status[b]] : "?"));
+            goto done;
+        }
+    }
+    DEC_TRY(hipMemcpy(left, d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H left");
+    if (info.channels == 2) DEC_TRY(hipMemcpy(right, d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H right");
+done:
+#undef DEC_TRY
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d_pay) (void)hipFree(d_pay);
+    if (d_offs) (void)hipFree(d_offs);
+    if (d_left) (void)hipFree(d_left);
+    if (d_right) (void)hipFree(d_right);
+    if (d_status) (void)hipFree(d_status);
+    if (d_ms) (void)hipFree(d_ms);
+    return rc;
+}
+
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
                   const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,
                   uint8_t** out, uint64_t* out_size) {

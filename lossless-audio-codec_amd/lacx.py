@@ -89,6 +89,7 @@ EXPORTS = (
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
     "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers", "lacx_encode_wav_view",
+    "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error",
 )
 
 
@@ -117,6 +118,7 @@ def lib():
         L.lacx_encoder_destroy.argtypes = [C.c_void_p]
         L.lacx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.lacx_device_count.restype = C.c_int
+        L.lacx_decode_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -463,6 +465,36 @@ def wav_parse(wav: bytes):
     buf = (C.c_uint8 * max(1, len(wav))).from_buffer_copy(wav if wav else b"\0")
     rc = lib().lacx_wav_parse(buf, C.c_uint64(len(wav)), C.byref(info))
     return info if rc == OK else None
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("blocks", C.c_uint32), ("frames", C.c_uint64), ("channels", C.c_uint8),
+                ("bit_depth", C.c_uint8), ("stereo_mode", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+def stream_parse(lac: bytes):
+    """Header + block table of a .lac (ref src/codec/lac/decoder.cpp:90-200); None when inconsistent.  Host-only."""
+    info = StreamInfo()
+    buf = (C.c_uint8 * max(1, len(lac))).from_buffer_copy(lac if lac else b"\0")
+    return info if lib().lacx_stream_parse(buf, C.c_uint64(len(lac)), C.byref(info)) == OK else None
+
+
+def decode(lac: bytes, device: int = -1):
+    """LAC::Decoder::decode on the device (ref src/codec/lac/decoder.hpp:10-24): (left, right or None, StreamInfo,
+    kernel milliseconds).  Raises RuntimeError("[decode-error] ...") like the reference throws."""
+    info = StreamInfo()
+    buf = (C.c_uint8 * max(1, len(lac))).from_buffer_copy(lac if lac else b"\0")
+    if lib().lacx_stream_parse(buf, C.c_uint64(len(lac)), C.byref(info)) != OK:
+        raise RuntimeError(lib().lacx_decode_last_error().decode(errors="replace"))
+    left = np.empty(info.frames, dtype=np.int32)
+    right = np.empty(info.frames, dtype=np.int32) if info.channels == 2 else None
+    ms = C.c_float()
+    rc = lib().lacx_decode(C.c_int(device), buf, C.c_uint64(len(lac)), left.ctypes.data_as(C.POINTER(C.c_int32)),
+                           right.ctypes.data_as(C.POINTER(C.c_int32)) if right is not None else None,
+                           C.c_uint64(info.frames), C.byref(ms))
+    if rc != OK:
+        raise RuntimeError(lib().lacx_decode_last_error().decode(errors="replace"))
+    return left, right, info, float(ms.value)
 
 
 def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:

@@ -147,3 +147,26 @@ def test_thread_count_one_means_no_extra_emit_workers(pkg):
         enc.set_thread_count(n)
         assert L.lacx_debug_emit_workers(enc._handle()) == want
         enc.close()
+
+
+def test_stream_parse_and_decode_without_a_device(pkg):
+    """lacx_stream_parse is host-only (header + block table consistency, ref lac/decoder.cpp:90-200); lacx_decode needs
+    the device and says so -- there is no CPU decoder behind the product API."""
+    path = os.path.join(ROOT, "tests", "golden", "small", "n16421_st16.lac")
+    lac = open(path, "rb").read()
+    info = pkg.lacx.stream_parse(lac)
+    assert (info.sample_rate, info.channels, info.bit_depth, info.stereo_mode, info.frames, info.blocks) == \
+        (48000, 2, 16, 2, 16421, 2)
+    assert pkg.lacx.stream_parse(lac[:-1]) is None          # payload shorter than the table says
+    assert pkg.lacx.stream_parse(lac + b"\0") is None       # trailing byte
+    assert pkg.lacx.stream_parse(b"LA\x02" + lac[3:]) is None  # version
+    assert pkg.lacx.stream_parse(lac[:13]) is None
+    bad = bytearray(lac)
+    bad[8] = 20  # bit depth
+    assert pkg.lacx.stream_parse(bytes(bad)) is None
+    bad = bytearray(lac)
+    bad[14:18] = (16385).to_bytes(4, "big")  # a block longer than 16384 frames
+    assert pkg.lacx.stream_parse(bytes(bad)) is None
+    if pkg.lacx.device_count() <= 0:
+        with pytest.raises(RuntimeError, match="no usable HIP device"):
+            pkg.lacx.decode(lac)
