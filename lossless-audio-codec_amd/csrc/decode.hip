@@ -26,7 +26,7 @@ namespace lacx {
 namespace {
 
 constexpr int kDecThreads = 64;
-constexpr uint32_t kModeRice = 0, kModeBin = 2, kModeStatic = 3;  // (1 = zero-run)  ref block/constants.hpp
+constexpr uint32_t kModeBin = 2, kModeStatic = 3;  // (0 = adaptive Rice, 1 = zero-run)  ref block/constants.hpp
 constexpr uint32_t kZeroRunMin = 4, kZeroRunK = 2;
 
 struct DecMem {  // one column per lane
@@ -35,20 +35,70 @@ struct DecMem {  // one column per lane
     int16_t coef[32][kDecThreads];    // the channel block's Q15 coefficients
 };
 
-// MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  The buffer is padded
-// with 16 zero bytes, so that a window fetched at the very end stays inside it; reading past nbits sets err.
+// MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  A lane's stream is
+// latency-bound -- every token's position depends on the one before -- so the reader keeps the next bits in a 64-bit
+// register (buf: `have` valid bits from r.pos on, left-aligned) and fetches the stream as big-endian 64-bit words one
+// word AHEAD of the one it is consuming (nxt), so that a load's latency lies under the decoding of 64 bits.  The buffer
+// is padded with 32 zero bytes, so that the read-ahead at the very end stays inside it; reading past nbits sets err.
 struct BitIn {
     const uint8_t* p;
     unsigned long long nbits, pos;
     uint32_t err;
+    unsigned long long buf, cur, nxt;  // cur: the word that holds bit r.pos + have; nxt: the word after it
+    uint32_t have;
+    unsigned long long widx;  // index of cur
 };
 
-__device__ __forceinline__ unsigned long long window(const BitIn& r) {  // >= 57 valid bits from r.pos on, left-aligned
-    const unsigned long long byte = r.pos >> 3;
+__device__ __forceinline__ unsigned long long load_word(const uint8_t* p, unsigned long long idx) {
     unsigned long long w;
-    __builtin_memcpy(&w, r.p + byte, 8);
-    w = __builtin_bswap64(w);
-    return w << (r.pos & 7u);
+    __builtin_memcpy(&w, p + 8ull * idx, 8);
+    return __builtin_bswap64(w);
+}
+__device__ __forceinline__ void reader_seek(BitIn& r, unsigned long long bitpos) {
+    r.pos = bitpos;
+    r.have = 0;
+    r.buf = 0;
+    r.widx = bitpos >> 6;
+    r.cur = load_word(r.p, r.widx);
+    r.nxt = load_word(r.p, r.widx + 1);
+}
+__device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, unsigned long long nbits) {
+    r.p = p;
+    r.nbits = nbits;
+    r.err = 0;
+    reader_seek(r, 0);
+}
+// tops the register up to at least 33 valid bits (a whole word's worth when the current word runs out)
+__device__ __forceinline__ void refill(BitIn& r) {
+    while (r.have <= 32u) {
+        const uint32_t o = (uint32_t)((r.pos + r.have) & 63u);       // offset of the first missing bit inside cur
+        const uint32_t room = 64u - r.have, left = 64u - o;
+        const uint32_t take = room < left ? room : left;             // >= 1
+        r.buf |= (r.cur << o) >> r.have;                             // bits beyond `take` are overwritten by later refills
+        r.buf &= ~0ull << (64u - (r.have + take));                   // ... so clear them now
+        r.have += take;
+        if (take == left) {  // cur is used up: move on, fetch one word further ahead
+            r.cur = r.nxt;
+            ++r.widx;
+            r.nxt = load_word(r.p, r.widx + 1);
+        }
+    }
+}
+__device__ __forceinline__ void consume(BitIn& r, uint32_t n) {  // n <= have
+    r.buf = n >= 64u ? 0ull : r.buf << n;
+    r.have -= n;
+    r.pos += n;
+}
+// n <= 32 bits that are already in the register (after a refill: at least 33, or all that is left of the block)
+__device__ __forceinline__ uint32_t take(BitIn& r, uint32_t n) {
+    if (n == 0) return 0;
+    if (r.pos + n > r.nbits) {
+        r.err = 1;
+        return 0;
+    }
+    const uint32_t v = (uint32_t)(r.buf >> (64u - n));
+    consume(r, n);
+    return v;
 }
 __device__ __forceinline__ uint32_t get_bits(BitIn& r, uint32_t n) {  // n <= 32
     if (n == 0) return 0;
@@ -56,8 +106,9 @@ __device__ __forceinline__ uint32_t get_bits(BitIn& r, uint32_t n) {  // n <= 32
         r.err = 1;
         return 0;
     }
-    const uint32_t v = (uint32_t)(window(r) >> (64u - n));
-    r.pos += n;
+    refill(r);
+    const uint32_t v = (uint32_t)(r.buf >> (64u - n));
+    consume(r, n);
     return v;
 }
 // unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86)
@@ -68,21 +119,25 @@ __device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q)
             r.err = 1;
             return false;
         }
-        const unsigned long long w = window(r) | 0x7Full;  // the low 7 bits are not valid: make them ones
-        uint32_t ones = (uint32_t)__clzll((long long)~w);  // 0..57 leading ones among the valid bits
+        refill(r);
+        const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero, so they read as terminators
+        const uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
         const unsigned long long left = r.nbits - r.pos;
-        if (ones > 57u) ones = 57u;
-        if ((unsigned long long)ones >= left) {  // ran into the end without a terminator
+        if (ones < r.have) {  // terminator inside the valid bits
+            if ((unsigned long long)ones >= left) {
+                r.err = 1;
+                return false;
+            }
+            c += ones;
+            consume(r, ones + 1u);
+            break;
+        }
+        if ((unsigned long long)r.have >= left) {  // all ones up to the end of the block
             r.err = 1;
             return false;
         }
-        if (ones < 57u) {
-            c += ones;
-            r.pos += ones + 1u;
-            break;
-        }
-        c += 57u;
-        r.pos += 57u;
+        c += r.have;
+        consume(r, r.have);
         if (c > (unsigned long long)max_q) return false;
     }
     if (c > (unsigned long long)max_q) return false;
@@ -140,87 +195,13 @@ __device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool statel
     return biased_k<false>(km, a.sum, a.sum - a.wsum, a.large | (a.zero << 16), a.count);
 }
 
-// One partition (ref block/decoder.cpp:88-330).  Residuals go to out[0..samples); 0 = ok, else a status code.
-__device__ uint32_t decode_segment(BitIn& r, uint32_t samples, uint32_t k0, uint32_t mode, int32_t* __restrict__ out,
-                                   bool stateless, DecMem& dm, int lane) {
-    Adapt a;
-    adapt_reset(a);
-    uint32_t k = k0;
-    if (mode == kModeStatic) {
-        for (uint32_t i = 0; i < samples; ++i) {
-            uint32_t u;
-            if (!get_rice(r, k0, u)) return 3;
-            if (u >> 30) return 9;
-            out[i] = unzigzag(u);
-        }
-        return 0;
-    }
-    if (mode == kModeRice) {
-        for (uint32_t i = 0; i < samples; ++i) {
-            uint32_t u;
-            if (!get_rice(r, k, u)) return 3;
-            if (u >> 30) return 9;
-            out[i] = unzigzag(u);
-            k = adapt_next(a, u, stateless, dm, lane);
-        }
-        return 0;
-    }
-    if (mode == kModeBin) {
-        for (uint32_t i = 0; i < samples; ++i) {
-            const uint32_t tag = get_bits(r, 2);
-            if (r.err) return 3;
-            uint32_t u = 0;
-            if (tag == 1u || tag == 2u) {
-                const uint32_t sgn = get_bits(r, 1);
-                if (r.err) return 3;
-                u = zigzag(sgn ? -(int32_t)tag : (int32_t)tag);
-            } else if (tag == 3u) {
-                if (!get_rice(r, k, u)) return 3;
-                if (u >> 30) return 9;
-            }
-            out[i] = unzigzag(u);
-            k = adapt_next(a, u, stateless, dm, lane);
-        }
-        return 0;
-    }
-    // zero-run mode
-    uint32_t idx = 0;
-    while (idx < samples) {
-        const uint32_t tag = get_bits(r, 2);
-        if (r.err || tag > 2u) return 3;
-        if (tag == 1u) {
-            uint32_t enc;
-            if (!get_rice(r, kZeroRunK, enc)) return 3;
-            const unsigned long long run = (unsigned long long)enc + kZeroRunMin;
-            if (run > (unsigned long long)(samples - idx)) return 3;
-            for (uint32_t j = 0; j < (uint32_t)run; ++j) out[idx + j] = 0;
-            idx += (uint32_t)run;
-            if (stateless) {  // the count jumps, the parameter is recomputed once (ref block/decoder.cpp zero-run branch)
-                a.count += (uint32_t)run;
-                const uint32_t km = kmean(a.sum, a.count);
-                k = km > 31u ? 31u : km;
-            } else {
-                for (uint32_t j = 0; j < (uint32_t)run; ++j) k = adapt_next(a, 0u, false, dm, lane);
-            }
-        } else {
-            uint32_t u;
-            if (tag == 0u) {
-                if (!get_rice(r, k, u)) return 3;
-            } else {
-                u = get_bits(r, 32);  // escape: the zigzag value verbatim
-                if (r.err) return 3;
-                u = zigzag(unzigzag(u));
-            }
-            if (u >> 30) return 9;
-            out[idx++] = unzigzag(u);
-            k = adapt_next(a, u, stateless, dm, lane);
-        }
-    }
-    return 0;
-}
-
-// One channel block: header, partition table, residual, zero padding to the byte, synthesis in place
-// (ref block/decoder.cpp:64-520).
+// One channel block: header, partition table, residual tokens, synthesis, zero padding to the byte
+// (ref block/decoder.cpp:64-520).  The 64 lanes of a wave decode 64 different blocks, so everything per sample is ONE loop
+// that every lane walks in step -- one sample per trip whatever the partition, its mode (data, not control flow: the
+// four token grammars are alternatives inside the trip), a zero run in progress (its zeros come out one per trip) or
+// the predictor (the synthesis of sample i follows its residual at once: it only needs earlier samples).  Written as
+// four loops per partition and a synthesis pass per predictor type, lanes in different loops would take turns.
+// 0 = ok, else a status code.
 __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restrict__ out, DecMem& dm, int lane) {
     const uint32_t type = get_bits(r, 8);
     const int order = (int)get_bits(r, 8);
@@ -234,6 +215,7 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     }
     if (type == 2u) {
         for (int i = 0; i < order; ++i) dm.coef[i][lane] = (int16_t)get_bits(r, 16);
+        for (int i = order; i < 12; ++i) dm.coef[i][lane] = 0;  // the synthesis always walks twelve taps
         if (r.err) return 2;
     }
     const uint32_t control = get_bits(r, 8);
@@ -244,69 +226,111 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     if (p > 0u && (n >> p) < (uint32_t)kMinPartition) return 2;
     const uint32_t parts = (p == 0u || (n >> p) == 0u) ? 1u : (1u << p);
     const uint32_t base = parts == 1u ? n : (n >> p);
-    const unsigned long long table_pos = r.pos;  // (mode:2, k:5) per partition, read again partition by partition
+    const unsigned long long table_pos = r.pos;  // (mode:2, k:5) per partition, read when the partition starts
     if (r.pos + 7ull * parts > r.nbits) return 2;
-    r.pos += 7ull * parts;
-    uint32_t off = 0;
-    for (uint32_t i = 0; i < parts; ++i) {
-        BitIn t = r;
-        t.pos = table_pos + 7ull * i;
-        const uint32_t mode = get_bits(t, 2), k0 = get_bits(t, 5);
-        if (i == 0u && mode != cmode) return 2;
-        const uint32_t len = (i + 1u == parts) ? n - base * (parts - 1u) : base;
-        const uint32_t st = decode_segment(r, len, k0, mode, out + off, p > 0u, dm, lane);
-        if (st) return st;
-        off += len;
+    reader_seek(r, r.pos + 7ull * parts);
+    const bool stateless = p > 0u;
+
+    Adapt a;
+    adapt_reset(a);
+    uint32_t mode = 0, k = 0, seg_end = 0, part = 0, zeros_left = 0, st = 0;
+    long long h1 = 0, h2 = 0, h3 = 0, h4 = 0;  // the last four samples (fixed / FIR predictors)
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i == seg_end) {  // a partition starts
+            BitIn t = r;
+            reader_seek(t, table_pos + 7ull * part);
+            mode = get_bits(t, 2);
+            k = get_bits(t, 5);
+            if (part == 0u && mode != cmode) {
+                st = 2;
+                break;
+            }
+            seg_end += (part + 1u == parts) ? n - base * (parts - 1u) : base;
+            ++part;
+            adapt_reset(a);
+        }
+        uint32_t u = 0;
+        bool adapt = mode != kModeStatic;  // a static partition keeps the k of its table entry
+        if (zeros_left) {  // inside a zero run: stateful streams adapt on every zero, stateless ones did it at the token
+            --zeros_left;
+            adapt = !stateless;
+        } else {
+            // One token, whatever the grammar: [2-bit tag] [unary quotient] [remainder / sign / 32-bit escape], each part
+            // present or not -- three trips through the bit reader at most, written once for all four modes.
+            const bool is_bin = mode == kModeBin, is_zr = mode == 1u, tagged = is_bin || is_zr;
+            refill(r);
+            const uint32_t tag = tagged ? take(r, 2) : 0u;
+            const bool run_token = is_zr && tag == 1u;
+            const bool has_unary = !tagged || (is_bin ? tag == 3u : tag <= 1u);
+            const uint32_t kk = run_token ? kZeroRunK : k;
+            const uint32_t rem_bits = has_unary ? kk : (is_bin ? ((tag == 1u || tag == 2u) ? 1u : 0u) : (tag == 2u ? 32u : 0u));
+            if (is_zr && tag == 3u) st = 3;
+            uint32_t q = 0;
+            if (has_unary && !get_unary(r, 0xFFFFFFFFu >> kk, q)) st = 3;
+            if (r.have < rem_bits) refill(r);
+            const uint32_t rem = take(r, rem_bits);
+            const uint32_t value = has_unary ? ((q << kk) | rem) : rem;
+            if (is_bin && (tag == 1u || tag == 2u)) {
+                u = zigzag(rem ? -(int32_t)tag : (int32_t)tag);  // +-1, +-2: tag and sign bit
+            } else if (run_token) {
+                const unsigned long long run = (unsigned long long)value + kZeroRunMin;
+                if (run > (unsigned long long)(seg_end - i)) st = 3;
+                zeros_left = (uint32_t)run - 1u;
+                if (stateless) {  // the count jumps by the run, the parameter is recomputed once
+                    a.count += (uint32_t)run;
+                    const uint32_t km = kmean(a.sum, a.count);
+                    k = km > 31u ? 31u : km;
+                    adapt = false;
+                }
+            } else {
+                u = value;  // Rice value, bin tag 0 (= 0), or the escape's verbatim zigzag value
+            }
+        }
+        if (r.err && !st) st = 3;
+        if (!st && (u >> 30)) st = 9;
+        if (st) break;
+        if (adapt) k = adapt_next(a, u, stateless, dm, lane);
+        // synthesis
+        long long s = unzigzag(u);
+        if (type == 2u) {
+            // Twelve taps unrolled, their 24 LDS reads in flight together (a loop to the lane's own order would pay one
+            // LDS round trip per tap); coefficients beyond the order are zero, taps that reach before the first sample
+            // are masked.  Orders above 12 (valid streams, none from this encoder) continue in a plain loop.
+            long long acc = 0;
+#pragma unroll
+            for (int t = 1; t <= 12; ++t) {
+                const long long c = (uint32_t)t <= i ? (long long)dm.coef[t - 1][lane] : 0ll;
+                acc += c * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
+            }
+            const int taps = order < (int)i ? order : (int)i;
+            for (int t = 13; t <= taps; ++t)
+                acc += (long long)dm.coef[t - 1][lane] * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
+            s += acc >> 15;
+        } else if (type == 1u) {
+            if (i >= 2u) s += (3 * h1 - h2) >> 2;
+        } else if (i >= (uint32_t)order) {
+            switch (order) {
+                case 1: s += h1; break;
+                case 2: s += 2 * h1 - h2; break;
+                case 3: s += 3 * h1 - 3 * h2 + h3; break;
+                case 4: s += 4 * h1 - 6 * h2 + 4 * h3 - h4; break;
+                default: break;
+            }
+        }
+        if (s < -2147483648ll || s > 2147483647ll) {
+            st = 5;
+            break;
+        }
+        out[i] = (int32_t)s;
+        if (type == 2u) dm.hist[i & 31u][lane] = (int32_t)s;
+        h4 = h3;
+        h3 = h2;
+        h2 = h1;
+        h1 = s;
     }
+    if (st) return st;
     while (r.pos & 7u) {  // zero padding to the byte (ref bit_reader.hpp consume_zero_padding_to_byte)
         if (get_bits(r, 1) || r.err) return 4;
-    }
-    // synthesis in place; the history of the last `order` samples rides in the lane's LDS column
-    if (type == 0u) {
-        long long h1 = 0, h2 = 0, h3 = 0, h4 = 0;  // out[i-1..i-4]
-        for (uint32_t i = 0; i < n; ++i) {
-            long long s = out[i];
-            if (i >= (uint32_t)order) {
-                long long pred = 0;
-                switch (order) {
-                    case 1: pred = h1; break;
-                    case 2: pred = 2 * h1 - h2; break;
-                    case 3: pred = 3 * h1 - 3 * h2 + h3; break;
-                    case 4: pred = 4 * h1 - 6 * h2 + 4 * h3 - h4; break;
-                    default: break;
-                }
-                s += pred;
-                if (s < -2147483648ll || s > 2147483647ll) return 5;
-                out[i] = (int32_t)s;
-            }
-            h4 = h3;
-            h3 = h2;
-            h2 = h1;
-            h1 = s;
-        }
-    } else if (type == 1u) {
-        long long h1 = 0, h2 = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            long long s = out[i];
-            if (i >= 2u) {
-                s += (3 * h1 - h2) >> 2;
-                if (s < -2147483648ll || s > 2147483647ll) return 5;
-                out[i] = (int32_t)s;
-            }
-            h2 = h1;
-            h1 = s;
-        }
-    } else {
-        for (uint32_t i = 0; i < n; ++i) {
-            long long acc = 0;
-            const int taps = order < (int)i ? order : (int)i;
-            for (int t = 1; t <= taps; ++t)
-                acc += (long long)dm.coef[t - 1][lane] * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
-            const long long s = (acc >> 15) + (long long)out[i];
-            if (s < -2147483648ll || s > 2147483647ll) return 5;
-            out[i] = (int32_t)s;
-            dm.hist[i & 31u][lane] = (int32_t)s;
-        }
     }
     return 0;
 }
@@ -326,10 +350,7 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(uint32_t num_blocks, int
     if (blk >= num_blocks) return;
     const uint32_t n = (uint32_t)(frame_off[blk + 1] - frame_off[blk]);
     BitIn r;
-    r.p = payload + byte_off[blk];
-    r.nbits = 8ull * (byte_off[blk + 1] - byte_off[blk]);
-    r.pos = 0;
-    r.err = 0;
+    reader_init(r, payload + byte_off[blk], 8ull * (byte_off[blk + 1] - byte_off[blk]));
     uint32_t st = 0;
     uint32_t ms = stereo_mode == 1 ? 1u : 0u;
     if (n == 0u || n > (uint32_t)kMaxBlock) st = 1;

@@ -1591,8 +1591,8 @@ int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, in
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<uint32_t> status(nb);
     if (device >= 0) DEC_TRY(hipSetDevice(device), "hipSetDevice");
-    DEC_TRY(hipMalloc((void**)&d_pay, pay + 16), "hipMalloc(payload)");
-    DEC_TRY(hipMemset(d_pay + pay, 0, 16), "memset");
+    DEC_TRY(hipMalloc((void**)&d_pay, pay + 32), "hipMalloc(payload)");  // the bit reader fetches up to three words ahead
+    DEC_TRY(hipMemset(d_pay + pay, 0, 32), "memset");
     DEC_TRY(hipMemcpy(d_pay, lac + head, pay, hipMemcpyHostToDevice), "H2D payload");
     DEC_TRY(hipMalloc((void**)&d_offs, offs.size() * sizeof(unsigned long long)), "hipMalloc(offsets)");
     DEC_TRY(hipMemcpy(d_offs, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "H2D offsets");

@@ -42,4 +42,13 @@ tail = payload.tobytes()[off:]
 lac = lacx.assemble(sr, bd, sm, 2, [(tail, table[b0:].copy())])
 ok = len(lac) == ent["lac_bytes"] and hashlib.sha256(lac).hexdigest() == ent["lac_sha256"]
 print("last eighth identical to the reference's shard:", ok)
+if os.environ.get("BIG_DECODE", "1") != "0":
+    # the whole 2 h stream through the device decoder: 21 094 lanes, one per block, all at once
+    whole = lacx.assemble(sr, bd, sm, 2, [(payload.tobytes(), table.copy())])
+    dl, dr, info, ms = lacx.decode(whole)
+    pcm = d.cpu().numpy().reshape(-1, 2)
+    same = bool(np.array_equal(dl, pcm[:, 0]) and np.array_equal(dr, pcm[:, 1]))
+    print(f"decode: kernels {ms:.1f} ms for {frames * 2 / 1e6:.0f} Msamples = {frames * 2 / ms / 1e3:.0f} Msamples/s, "
+          f"{info.blocks} blocks, PCM identical: {same}", flush=True)
+    ok = ok and same
 sys.exit(0 if ok else 1)
