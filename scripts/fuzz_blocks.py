@@ -58,7 +58,11 @@ for it in range(n_streams):
     if got != want:
         bad += 1
         print("STREAM MISMATCH", it, dict(ch=ch, bd=bd, sr=sr, sm=sm, frames=frames, kind=kind, zr=zr, pt=pt))
-print(f"streams: {n_streams - bad}/{n_streams} identical, {time.time() - t0:.1f}s")
+    dl, dr, _, _ = lacx.decode(got)  # and back through the device decoder
+    if not np.array_equal(dl, left) or (right is not None and not np.array_equal(dr, right)):
+        bad += 1
+        print("DECODE MISMATCH", it, dict(ch=ch, bd=bd, sr=sr, sm=sm, frames=frames, kind=kind, zr=zr, pt=pt))
+print(f"streams: {n_streams - bad}/{n_streams} identical and decoded back, {time.time() - t0:.1f}s")
 be = lacx.BlockEncoder()
 badb = 0
 t0 = time.time()
