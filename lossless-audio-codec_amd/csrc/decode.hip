@@ -68,20 +68,24 @@ __device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, unsigned
     r.err = 0;
     reader_seek(r, 0);
 }
-// tops the register up to at least 33 valid bits (a whole word's worth when the current word runs out)
+// tops the register up: afterwards it holds at least 57 valid bits (two steps at most: the rest of the current word,
+// then as much of the next one as fits)
+__device__ __forceinline__ void refill_step(BitIn& r) {
+    const uint32_t o = (uint32_t)((r.pos + r.have) & 63u);  // offset of the first missing bit inside cur
+    const uint32_t room = 64u - r.have, left = 64u - o;
+    const uint32_t take = room < left ? room : left;
+    r.buf |= room ? (r.cur << o) >> (r.have & 63u) : 0ull;  // the low bits of buf beyond `have` are zero (invariant)
+    r.have += take;
+    if (take == left) {  // cur is used up: move on, fetch one word further ahead
+        r.cur = r.nxt;
+        ++r.widx;
+        r.nxt = load_word(r.p, r.widx + 1);
+    }
+}
 __device__ __forceinline__ void refill(BitIn& r) {
-    while (r.have <= 32u) {
-        const uint32_t o = (uint32_t)((r.pos + r.have) & 63u);       // offset of the first missing bit inside cur
-        const uint32_t room = 64u - r.have, left = 64u - o;
-        const uint32_t take = room < left ? room : left;             // >= 1
-        r.buf |= (r.cur << o) >> r.have;                             // bits beyond `take` are overwritten by later refills
-        r.buf &= ~0ull << (64u - (r.have + take));                   // ... so clear them now
-        r.have += take;
-        if (take == left) {  // cur is used up: move on, fetch one word further ahead
-            r.cur = r.nxt;
-            ++r.widx;
-            r.nxt = load_word(r.p, r.widx + 1);
-        }
+    if (r.have <= 56u) {
+        refill_step(r);
+        if (r.have <= 56u) refill_step(r);
     }
 }
 __device__ __forceinline__ void consume(BitIn& r, uint32_t n) {  // n <= have
