@@ -201,7 +201,8 @@ int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const 
 /* ---- decode: LAC::Decoder::decode, ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
  * src/codec/block/decoder.cpp:64-520.  The product's own check that a .lac gives back the PCM, on the device: one lane
  * per block (the format serialises everything inside a block), all blocks of the stream at once.
- * lacx_stream_parse: host only; header + block table consistency (LACX_E_INVALID otherwise).
+ * lacx_stream_parse: host only; the reference reader's structural rules for the header and the block table (version 3;
+ * its 1 GiB cap on the decoded PCM is not taken over), LACX_E_INVALID otherwise.
  * lacx_decode: left / right (right may be null for mono) are caller-owned arrays of `frames` int32 each; a malformed
  * block, a sample outside the bit depth or a residual magnitude the encoder's domain cannot produce (>= 2^30) gives
  * LACX_E_RUNTIME ("[decode-error] block=N ..." in lacx_decode_last_error, the reference throws std::runtime_error with

@@ -1525,25 +1525,38 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 
 const char* lacx_decode_last_error(void) { return g_decode_err.c_str(); }
 
-// Container header + block table (ref src/codec/frame/frame_header.hpp:25-60, lac/decoder.cpp:90-200): magic, version 3,
-// channels, stereo mode, rate, depth, reserved byte, block count, (frames, bytes) per block; the sizes must add up.
+// Container header + block table: the structural rules of the reference's reader (src/codec/frame/frame_header.hpp:48-74,
+// lac/decoder.cpp:84-145) -- sync, version 3, channels, stereo mode (0 for mono), one of the four sample rates, depth,
+// reserved byte; at least one block; every block 1..16384 frames, non-final ones at least 256; non-zero compressed
+// sizes that add up to the file; at most 6 912 000 000 samples and a WAV that RIFF can hold.  NOT taken over: its cap on
+// the decoded PCM (1 GiB) and the block count that follows from it, which would refuse the 2 h stream of BASELINE
+// configs[3]; and the legacy version-2 container (no compressed sizes, hence no parallelism).
 int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out) {
     if (!lac || !out) return decode_fail(LACX_E_INVALID, "null argument");
-    if (size < 14 || lac[0] != 0x4C || lac[1] != 0x41 || lac[2] != 3) return decode_fail(LACX_E_INVALID, "[decode-error] bad header");
+    if (size == 0) return decode_fail(LACX_E_INVALID, "[decode-error] empty input");
+    if (size < 10 || lac[0] != 0x4C || lac[1] != 0x41 || lac[2] != 3) return decode_fail(LACX_E_INVALID, "[decode-error] invalid frame header");
     const int ch = lac[3], sm = lac[4], bd = lac[8];
     const uint32_t sr = ((uint32_t)lac[5] << 8) | lac[6] | ((uint32_t)lac[7] << 16);
-    if ((ch != 1 && ch != 2) || sm > 2 || (bd != 16 && bd != 24) || lac[9] != 0)
-        return decode_fail(LACX_E_INVALID, "[decode-error] bad header");
+    const bool rate_ok = sr == 44100 || sr == 48000 || sr == 96000 || sr == 192000;
+    if ((ch != 1 && ch != 2) || sm > 2 || (ch == 1 && sm != 0) || !rate_ok || (bd != 16 && bd != 24) || lac[9] != 0)
+        return decode_fail(LACX_E_INVALID, "[decode-error] invalid frame header");
+    if (size < 14) return decode_fail(LACX_E_INVALID, "[decode-error] invalid block count");
     const uint32_t nb = be32(lac + 10);
-    if (size < 14 + 8ull * nb) return decode_fail(LACX_E_INVALID, "[decode-error] truncated block table");
+    if (nb == 0) return decode_fail(LACX_E_INVALID, "[decode-error] invalid block count");
+    if (size < 14 + 8ull * nb) return decode_fail(LACX_E_INVALID, "[decode-error] truncated block size table");
     uint64_t frames = 0, pay = 0;
     for (uint32_t b = 0; b < nb; ++b) {
         const uint32_t n = be32(lac + 14 + 8ull * b), by = be32(lac + 18 + 8ull * b);
-        if (n == 0 || n > (uint32_t)kMaxBlock || by == 0) return decode_fail(LACX_E_INVALID, "[decode-error] bad block table entry");
+        if (n == 0 || n > (uint32_t)kMaxBlock || (b + 1 < nb && n < 256u)) return decode_fail(LACX_E_INVALID, "[decode-error] invalid block size");
+        if (by == 0) return decode_fail(LACX_E_INVALID, "[decode-error] invalid compressed block size");
         frames += n;
         pay += by;
+        if (frames > 6912000000ull) return decode_fail(LACX_E_INVALID, "[decode-error] total samples exceed maximum");
+        if (pay > size) return decode_fail(LACX_E_INVALID, "[decode-error] compressed block sizes exceed frame payload");
     }
-    if (14 + 8ull * nb + pay != size) return decode_fail(LACX_E_INVALID, "[decode-error] sizes do not add up");
+    const uint64_t wav_bytes = frames * (uint64_t)ch * (uint64_t)(bd / 8);
+    if (36u + wav_bytes + (wav_bytes & 1u) > 0xFFFFFFFFull) return decode_fail(LACX_E_INVALID, "[decode-error] decoded WAV data exceeds RIFF limit");
+    if (14 + 8ull * nb + pay != size) return decode_fail(LACX_E_INVALID, "[decode-error] block payloads do not fill the file");
     out->sample_rate = sr;
     out->blocks = nb;
     out->frames = frames;
@@ -1562,7 +1575,6 @@ int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, in
     if (!left || (info.channels == 2 && !right)) return decode_fail(LACX_E_INVALID, "output arrays missing");
     if (frames != info.frames) return decode_fail(LACX_E_INVALID, "output arrays do not match the stream's frame count");
     if (device_ms) *device_ms = 0.f;
-    if (info.blocks == 0) return LACX_OK;
     if (lacx_device_count() <= 0) return decode_fail(LACX_E_DEVICE, "no usable HIP device");
 #define DEC_TRY(call, what)                                                                                  \
     do {                                                                                                     \

@@ -167,6 +167,19 @@ def test_stream_parse_and_decode_without_a_device(pkg):
     bad = bytearray(lac)
     bad[14:18] = (16385).to_bytes(4, "big")  # a block longer than 16384 frames
     assert pkg.lacx.stream_parse(bytes(bad)) is None
+    bad = bytearray(lac)
+    bad[14:18] = (255).to_bytes(4, "big")  # a non-final block below the canonical minimum of 256 frames
+    assert pkg.lacx.stream_parse(bytes(bad)) is None
+    bad = bytearray(lac)
+    bad[5:8] = bytes([0x56, 0x22, 0x00])  # 22050 Hz: not one of the four rates (low 16 bits big-endian, then bits 16..23)
+    assert pkg.lacx.stream_parse(bytes(bad)) is None
+    bad = bytearray(lac)
+    bad[10:14] = (0).to_bytes(4, "big")  # no blocks
+    assert pkg.lacx.stream_parse(bytes(bad[:14])) is None
+    mono = bytearray(open(os.path.join(ROOT, "tests", "golden", "small", "n33_mono16.lac"), "rb").read())
+    assert pkg.lacx.stream_parse(bytes(mono)) is not None
+    mono[4] = 2  # a stereo mode on a mono stream
+    assert pkg.lacx.stream_parse(bytes(mono)) is None
     if pkg.lacx.device_count() <= 0:
         with pytest.raises(RuntimeError, match="no usable HIP device"):
             pkg.lacx.decode(lac)
