@@ -13,7 +13,10 @@ for rnd in range(6):
         n = int(rng.integers(1, L.size))
         enc = lacx.Encoder(12, int(rng.integers(0, 3)), 48000, 16)
         enc.set_host_emit(bool(it & 1))
-        enc.encode(L[:n], R[:n])
+        lac = enc.encode(L[:n], R[:n])
+        if it % 5 == 0:  # and back through the device decoder (allocates and frees its buffers per call)
+            dl, dr, _, _ = lacx.decode(lac)
+            assert np.array_equal(dl, L[:n]) and np.array_equal(dr, R[:n])
         if it % 3 == 0:
             enc.set_host_emit(False)
             enc.encode_shard_pcm_device_view(inter.data_ptr(), lacx.PCM_INTERLEAVED_I16, 2, n, 0)
