@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "analyze_core.h"
 #include "kernels.h"
@@ -29,11 +30,18 @@ constexpr int kDecThreads = 64;
 constexpr uint32_t kModeBin = 2, kModeStatic = 3;  // (0 = adaptive Rice, 1 = zero-run)  ref block/constants.hpp
 constexpr uint32_t kZeroRunMin = 4, kZeroRunK = 2;
 
-struct DecMem {  // one column per lane
-    uint32_t ring[256][kDecThreads];  // the last 256 residual magnitudes (stateful adaptation's drift window)
-    int32_t hist[32][kDecThreads];    // the last 32 reconstructed samples (LPC orders up to 32 are valid streams)
-    int16_t coef[32][kDecThreads];    // the channel block's Q15 coefficients
+// Per-lane state that must be indexed, in LDS, one column per ACTIVE lane (row stride = active lanes of the wave, so a
+// wave that decodes one block needs 1.3 KiB and many such waves share a CU).
+struct DecMem {
+    uint32_t* ring_;  // [256][cols] the last 256 residual magnitudes (stateful adaptation's drift window)
+    int32_t* hist_;   // [32][cols]  the last 32 reconstructed samples (only LPC orders above 12 read it)
+    int16_t* coef_;   // [32][cols]  the channel block's Q15 coefficients
+    uint32_t cols;
+    __device__ __forceinline__ uint32_t& ring(uint32_t slot, int lane) { return ring_[slot * cols + (uint32_t)lane]; }
+    __device__ __forceinline__ int32_t& hist(uint32_t slot, int lane) { return hist_[slot * cols + (uint32_t)lane]; }
+    __device__ __forceinline__ int16_t& coef(uint32_t slot, int lane) { return coef_[slot * cols + (uint32_t)lane]; }
 };
+constexpr size_t kDecBytesPerCol = 256 * 4 + 32 * 4 + 32 * 2;
 
 // MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  A lane's stream is
 // latency-bound -- every token's position depends on the one before -- so the reader keeps the next bits in a 64-bit
@@ -44,22 +52,24 @@ struct BitIn {
     const uint8_t* p;
     unsigned long long nbits, pos;
     uint32_t err;
-    unsigned long long buf, cur, nxt;  // cur: the word that holds bit r.pos + have; nxt: the word after it
+    unsigned long long buf, cur, nxt;  // cur: the word that holds bit r.pos + have; nxt: the word after it, still raw
     uint32_t have;
     unsigned long long widx;  // index of cur
 };
 
+// the word as it lies in memory; it is byte-swapped only when it becomes the current word, so that nothing touches the
+// result of the read-ahead load (and waits for it) before it is needed
 __device__ __forceinline__ unsigned long long load_word(const uint8_t* p, unsigned long long idx) {
     unsigned long long w;
     __builtin_memcpy(&w, p + 8ull * idx, 8);
-    return __builtin_bswap64(w);
+    return w;
 }
 __device__ __forceinline__ void reader_seek(BitIn& r, unsigned long long bitpos) {
     r.pos = bitpos;
     r.have = 0;
     r.buf = 0;
     r.widx = bitpos >> 6;
-    r.cur = load_word(r.p, r.widx);
+    r.cur = __builtin_bswap64(load_word(r.p, r.widx));
     r.nxt = load_word(r.p, r.widx + 1);
 }
 __device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, unsigned long long nbits) {
@@ -77,7 +87,7 @@ __device__ __forceinline__ void refill_step(BitIn& r) {
     r.buf |= room ? (r.cur << o) >> (r.have & 63u) : 0ull;  // the low bits of buf beyond `have` are zero (invariant)
     r.have += take;
     if (take == left) {  // cur is used up: move on, fetch one word further ahead
-        r.cur = r.nxt;
+        r.cur = __builtin_bswap64(r.nxt);
         ++r.widx;
         r.nxt = load_word(r.p, r.widx + 1);
     }
@@ -178,12 +188,13 @@ __device__ __forceinline__ void adapt_reset(Adapt& a) {
 __device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool stateless, DecMem& dm, int lane) {
     a.sum += u;
     ++a.count;
-    const uint32_t km = kmean(a.sum, a.count);
+    // 32-bit form while the sum allows it (it does for every block of ordinary material)
+    const uint32_t km = (a.sum >> 31) == 0ull ? kmean32((uint32_t)a.sum, a.count) : kmean(a.sum, a.count);
     if (stateless) return km > 31u ? 31u : km;
     // drift window: the last 256 magnitudes
     const uint32_t slot = (a.count - 1u) & 255u;
-    if (a.count > 256u) a.wsum -= dm.ring[slot][lane];
-    dm.ring[slot][lane] = u;
+    if (a.count > 256u) a.wsum -= dm.ring(slot, lane);
+    dm.ring(slot, lane) = u;
     a.wsum += u;
     // micro window: flags of the last 96 samples
     const uint32_t q = km >= 31u ? 0u : (u >> km);
@@ -218,8 +229,8 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
         return 2;
     }
     if (type == 2u) {
-        for (int i = 0; i < order; ++i) dm.coef[i][lane] = (int16_t)get_bits(r, 16);
-        for (int i = order; i < 12; ++i) dm.coef[i][lane] = 0;  // the synthesis always walks twelve taps
+        for (int i = 0; i < order; ++i) dm.coef((uint32_t)i, lane) = (int16_t)get_bits(r, 16);
+        for (int i = order; i < 12; ++i) dm.coef((uint32_t)i, lane) = 0;  // the synthesis always walks twelve taps
         if (r.err) return 2;
     }
     const uint32_t control = get_bits(r, 8);
@@ -238,7 +249,14 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     Adapt a;
     adapt_reset(a);
     uint32_t mode = 0, k = 0, seg_end = 0, part = 0, zeros_left = 0, st = 0;
-    long long h1 = 0, h2 = 0, h3 = 0, h4 = 0;  // the last four samples (fixed / FIR predictors)
+    // The last twelve samples and the first twelve coefficients live in registers (a window that moves by one per trip):
+    // a tap is one multiply-add instead of two dependent LDS reads.  Fixed / FIR predictors use hw[0..3].
+    int32_t hw[12], cw[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        hw[t] = 0;
+        cw[t] = (type == 2u) ? (int32_t)dm.coef((uint32_t)t, lane) : 0;  // zero beyond the order
+    }
     for (uint32_t i = 0; i < n; ++i) {
         if (i == seg_end) {  // a partition starts
             BitIn t = r;
@@ -296,19 +314,17 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
         if (adapt) k = adapt_next(a, u, stateless, dm, lane);
         // synthesis
         long long s = unzigzag(u);
+        const long long h1 = hw[0], h2 = hw[1], h3 = hw[2], h4 = hw[3];
         if (type == 2u) {
-            // Twelve taps unrolled, their 24 LDS reads in flight together (a loop to the lane's own order would pay one
-            // LDS round trip per tap); coefficients beyond the order are zero, taps that reach before the first sample
-            // are masked.  Orders above 12 (valid streams, none from this encoder) continue in a plain loop.
+            // hw[t-1] = sample i - t; before the first sample the window holds zeros, which is what "taps that reach
+            // before the block start are left out" amounts to.  Orders above 12 (valid streams, none from this encoder)
+            // take their remaining taps from the history in LDS.
             long long acc = 0;
 #pragma unroll
-            for (int t = 1; t <= 12; ++t) {
-                const long long c = (uint32_t)t <= i ? (long long)dm.coef[t - 1][lane] : 0ll;
-                acc += c * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
-            }
+            for (int t = 0; t < 12; ++t) acc += (long long)cw[t] * (long long)hw[t];
             const int taps = order < (int)i ? order : (int)i;
             for (int t = 13; t <= taps; ++t)
-                acc += (long long)dm.coef[t - 1][lane] * (long long)dm.hist[(i - (uint32_t)t) & 31u][lane];
+                acc += (long long)dm.coef((uint32_t)t - 1u, lane) * (long long)dm.hist((i - (uint32_t)t) & 31u, lane);
             s += acc >> 15;
         } else if (type == 1u) {
             if (i >= 2u) s += (3 * h1 - h2) >> 2;
@@ -326,11 +342,10 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
             break;
         }
         out[i] = (int32_t)s;
-        if (type == 2u) dm.hist[i & 31u][lane] = (int32_t)s;
-        h4 = h3;
-        h3 = h2;
-        h2 = h1;
-        h1 = s;
+        if (type == 2u && order > 12) dm.hist(i & 31u, lane) = (int32_t)s;
+#pragma unroll
+        for (int t = 11; t > 0; --t) hw[t] = hw[t - 1];
+        hw[0] = (int32_t)s;
     }
     if (st) return st;
     while (r.pos & 7u) {  // zero padding to the byte (ref bit_reader.hpp consume_zero_padding_to_byte)
@@ -341,16 +356,24 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
 
 }  // namespace
 
+// lanes_per_wave (a power of two, 1..64): how many blocks one wave decodes -- fewer blocks per wave mean more waves to
+// interleave on a SIMD while the stream has few enough blocks that the idle lanes do not matter (the launcher picks).
 __global__ __launch_bounds__(kDecThreads) void k_decode(uint32_t num_blocks, int channels, int stereo_mode,
+                                                        uint32_t lanes_per_wave,
                                                         const uint8_t* __restrict__ payload,
                                                         const unsigned long long* __restrict__ byte_off,
                                                         const unsigned long long* __restrict__ frame_off,
                                                         int32_t* __restrict__ left, int32_t* __restrict__ right,
                                                         uint32_t* __restrict__ status, uint8_t* __restrict__ ms_flag) {
     extern __shared__ __align__(16) unsigned char dec_raw[];
-    DecMem& dm = *reinterpret_cast<DecMem*>(dec_raw);
+    DecMem dm;
+    dm.cols = lanes_per_wave;
+    dm.ring_ = reinterpret_cast<uint32_t*>(dec_raw);
+    dm.hist_ = reinterpret_cast<int32_t*>(dec_raw + (size_t)256 * 4 * lanes_per_wave);
+    dm.coef_ = reinterpret_cast<int16_t*>(dec_raw + (size_t)(256 + 32) * 4 * lanes_per_wave);
     const int lane = (int)threadIdx.x;
-    const uint32_t blk = blockIdx.x * (uint32_t)kDecThreads + threadIdx.x;
+    if ((uint32_t)lane >= lanes_per_wave) return;
+    const uint32_t blk = blockIdx.x * lanes_per_wave + threadIdx.x;
     if (blk >= num_blocks) return;
     const uint32_t n = (uint32_t)(frame_off[blk + 1] - frame_off[blk]);
     BitIn r;
@@ -396,17 +419,21 @@ __global__ __launch_bounds__(256) void k_ms_inverse(int channels, int bit_depth,
     if (bad) atomicMax(&status[blk], 7u);
 }
 
-size_t decode_smem_bytes() { return sizeof(DecMem); }
-
 hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
                          const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,
                          int32_t* right, uint32_t* status, uint8_t* ms_flag, hipStream_t stream) {
     if (num_blocks == 0) return hipSuccess;
+    uint32_t lanes = 64;  // blocks per wave (see k_decode)
+    if (const char* v = std::getenv("LACX_DECODE_LANES")) {  // tuning knob: 1, 2, 4, ... 64
+        const int x = std::atoi(v);
+        if (x >= 1 && x <= 64 && (x & (x - 1)) == 0) lanes = (uint32_t)x;
+    }
+    const size_t smem = kDecBytesPerCol * lanes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sizeof(DecMem));
+                                       (int)(kDecBytesPerCol * 64));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_decode, dim3((num_blocks + kDecThreads - 1) / kDecThreads), dim3(kDecThreads), sizeof(DecMem), stream,
-                       num_blocks, channels, stereo_mode, payload, byte_off, frame_off, left, right, status, ms_flag);
+    hipLaunchKernelGGL(k_decode, dim3((num_blocks + lanes - 1) / lanes), dim3(kDecThreads), smem, stream, num_blocks, channels,
+                       stereo_mode, lanes, payload, byte_off, frame_off, left, right, status, ms_flag);
     hipLaunchKernelGGL(k_ms_inverse, dim3(num_blocks, kMaxBlock / 1024), dim3(256), 0, stream, channels, bit_depth, frame_off,
                        left, right, (const uint8_t*)ms_flag, status);
     return hipGetLastError();
