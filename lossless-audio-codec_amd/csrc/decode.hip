@@ -45,126 +45,105 @@ constexpr size_t kDecBytesPerCol = 256 * 4 + 32 * 4 + 32 * 2;
 
 // MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  A lane's stream is
 // latency-bound -- every token's position depends on the one before -- so the reader keeps the next bits in a 64-bit
-// register (buf: `have` valid bits from r.pos on, left-aligned) and fetches the stream as big-endian 64-bit words one
-// word AHEAD of the one it is consuming (nxt), so that a load's latency lies under the decoding of 64 bits.  The buffer
-// is padded with 32 zero bytes, so that the read-ahead at the very end stays inside it; reading past nbits sets err.
+// register (buf: `have` valid bits from r.pos on, left-aligned, zeros below) and fetches the stream as 64-bit words one
+// word AHEAD of the one it is consuming (nxt, byte-swapped only when it becomes current, so that nothing waits for the
+// load before it is needed).  Positions are 32-bit, relative to the block (a block's bitstream is far below 2^32 bits).
+// Bounds are not checked read by read: a read past the end of the block yields bits of the next block or of the 32
+// zero bytes behind the payload (always mapped), and the caller compares r.pos with r.nbits once per trip (overrun());
+// only the unbounded loop of a long unary run checks as it goes.
 struct BitIn {
     const uint8_t* p;
-    unsigned long long nbits, pos;
-    uint32_t err;
+    uint32_t nbits, pos, have, widx;  // widx: index of cur
     unsigned long long buf, cur, nxt;  // cur: the word that holds bit r.pos + have; nxt: the word after it, still raw
-    uint32_t have;
-    unsigned long long widx;  // index of cur
 };
 
-// the word as it lies in memory; it is byte-swapped only when it becomes the current word, so that nothing touches the
-// result of the read-ahead load (and waits for it) before it is needed
-__device__ __forceinline__ unsigned long long load_word(const uint8_t* p, unsigned long long idx) {
+__device__ __forceinline__ unsigned long long load_word(const uint8_t* p, uint32_t idx) {
     unsigned long long w;
     __builtin_memcpy(&w, p + 8ull * idx, 8);
     return w;
 }
-__device__ __forceinline__ void reader_seek(BitIn& r, unsigned long long bitpos) {
+__device__ __forceinline__ void reader_seek(BitIn& r, uint32_t bitpos) {
     r.pos = bitpos;
     r.have = 0;
     r.buf = 0;
     r.widx = bitpos >> 6;
     r.cur = __builtin_bswap64(load_word(r.p, r.widx));
-    r.nxt = load_word(r.p, r.widx + 1);
+    r.nxt = load_word(r.p, r.widx + 1u);
 }
-__device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, unsigned long long nbits) {
+__device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, uint32_t nbits) {
     r.p = p;
     r.nbits = nbits;
-    r.err = 0;
     reader_seek(r, 0);
 }
-// tops the register up: afterwards it holds at least 57 valid bits (two steps at most: the rest of the current word,
-// then as much of the next one as fits)
+__device__ __forceinline__ bool overrun(const BitIn& r) { return r.pos > r.nbits; }
+// one step of topping the register up: the rest of the current word, or as much of it as fits
 __device__ __forceinline__ void refill_step(BitIn& r) {
-    const uint32_t o = (uint32_t)((r.pos + r.have) & 63u);  // offset of the first missing bit inside cur
+    const uint32_t o = (r.pos + r.have) & 63u;  // offset of the first missing bit inside cur
     const uint32_t room = 64u - r.have, left = 64u - o;
     const uint32_t take = room < left ? room : left;
-    r.buf |= room ? (r.cur << o) >> (r.have & 63u) : 0ull;  // the low bits of buf beyond `have` are zero (invariant)
+    r.buf |= (r.cur << o) >> r.have;  // have < 64 here; the low bits of buf beyond `have` are zero (invariant)
     r.have += take;
     if (take == left) {  // cur is used up: move on, fetch one word further ahead
         r.cur = __builtin_bswap64(r.nxt);
         ++r.widx;
-        r.nxt = load_word(r.p, r.widx + 1);
+        r.nxt = load_word(r.p, r.widx + 1u);
     }
 }
+// afterwards the register holds at least 33 valid bits (two steps at most)
 __device__ __forceinline__ void refill(BitIn& r) {
-    if (r.have <= 56u) {
+    if (r.have <= 32u) {
         refill_step(r);
-        if (r.have <= 56u) refill_step(r);
+        if (r.have <= 32u) refill_step(r);
     }
 }
-__device__ __forceinline__ void consume(BitIn& r, uint32_t n) {  // n <= have
-    r.buf = n >= 64u ? 0ull : r.buf << n;
+__device__ __forceinline__ void consume(BitIn& r, uint32_t n) {  // n <= have <= 64
+    r.buf = (r.buf << (n >> 1)) << (n - (n >> 1));  // two shifts: n may be 64
     r.have -= n;
     r.pos += n;
 }
-// n <= 32 bits that are already in the register (after a refill: at least 33, or all that is left of the block)
+// n <= 32 bits that are already in the register
 __device__ __forceinline__ uint32_t take(BitIn& r, uint32_t n) {
-    if (n == 0) return 0;
-    if (r.pos + n > r.nbits) {
-        r.err = 1;
-        return 0;
-    }
-    const uint32_t v = (uint32_t)(r.buf >> (64u - n));
+    const uint32_t v = n ? (uint32_t)(r.buf >> (64u - n)) : 0u;
     consume(r, n);
     return v;
 }
 __device__ __forceinline__ uint32_t get_bits(BitIn& r, uint32_t n) {  // n <= 32
-    if (n == 0) return 0;
-    if (r.pos + n > r.nbits) {
-        r.err = 1;
-        return 0;
-    }
     refill(r);
-    const uint32_t v = (uint32_t)(r.buf >> (64u - n));
-    consume(r, n);
-    return v;
+    return take(r, n);
 }
-// unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86)
+// unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86).  Expects a
+// refilled register; the common case -- the terminator is among the bits at hand -- is a count-leading-ones.
 __device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q) {
+    const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero, so they read as terminators
+    uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
+    if (ones < r.have) {
+        consume(r, ones + 1u);
+        q = ones;
+        return ones <= max_q;
+    }
     unsigned long long c = 0;
-    for (;;) {
-        if (r.pos >= r.nbits) {
-            r.err = 1;
-            return false;
-        }
+    for (;;) {  // a long run: register by register, with an eye on the end of the block
+        c += r.have;
+        consume(r, r.have);
+        if (c > (unsigned long long)max_q || r.pos >= r.nbits) return false;
         refill(r);
-        const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero, so they read as terminators
-        const uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
-        const unsigned long long left = r.nbits - r.pos;
-        if (ones < r.have) {  // terminator inside the valid bits
-            if ((unsigned long long)ones >= left) {
-                r.err = 1;
-                return false;
-            }
+        const unsigned long long iv = ~r.buf;
+        ones = iv ? (uint32_t)__clzll((long long)iv) : 64u;
+        if (ones < r.have) {
             c += ones;
             consume(r, ones + 1u);
             break;
         }
-        if ((unsigned long long)r.have >= left) {  // all ones up to the end of the block
-            r.err = 1;
-            return false;
-        }
-        c += r.have;
-        consume(r, r.have);
-        if (c > (unsigned long long)max_q) return false;
     }
-    if (c > (unsigned long long)max_q) return false;
     q = (uint32_t)c;
-    return true;
+    return c <= (unsigned long long)max_q;
 }
-__device__ __forceinline__ bool get_rice(BitIn& r, uint32_t k, uint32_t& value) {
-    if (k > 31u) return false;
+__device__ __forceinline__ bool get_rice(BitIn& r, uint32_t k, uint32_t& value) {  // k <= 31
+    refill(r);
     uint32_t q = 0;
     if (!get_unary(r, 0xFFFFFFFFu >> k, q)) return false;
-    const uint32_t rem = get_bits(r, k);
-    if (r.err) return false;
-    value = (q << k) | rem;
+    if (r.have < k) refill(r);
+    value = (q << k) | take(r, k);
     return true;
 }
 __device__ __forceinline__ int32_t unzigzag(uint32_t u) {
@@ -220,7 +199,7 @@ __device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool statel
 __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restrict__ out, DecMem& dm, int lane) {
     const uint32_t type = get_bits(r, 8);
     const int order = (int)get_bits(r, 8);
-    if (r.err || type > 2u) return 2;
+    if (overrun(r) || type > 2u) return 2;
     if (type == 2u) {
         if (order <= 0 || order > 32 || (uint32_t)order >= n) return 2;
     } else if (type == 1u) {
@@ -231,19 +210,19 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     if (type == 2u) {
         for (int i = 0; i < order; ++i) dm.coef((uint32_t)i, lane) = (int16_t)get_bits(r, 16);
         for (int i = order; i < 12; ++i) dm.coef((uint32_t)i, lane) = 0;  // the synthesis always walks twelve taps
-        if (r.err) return 2;
+        if (overrun(r)) return 2;
     }
     const uint32_t control = get_bits(r, 8);
-    if (r.err || (control & 0x10u)) return 2;
+    if (overrun(r) || (control & 0x10u)) return 2;
     const bool pflag = (control & 0x80u) != 0u;
     const uint32_t p = control & 0x0Fu, cmode = (control >> 5) & 3u;
     if ((pflag && p == 0u) || (!pflag && p != 0u) || p > (uint32_t)kMaxPartitionOrder) return 2;
     if (p > 0u && (n >> p) < (uint32_t)kMinPartition) return 2;
     const uint32_t parts = (p == 0u || (n >> p) == 0u) ? 1u : (1u << p);
     const uint32_t base = parts == 1u ? n : (n >> p);
-    const unsigned long long table_pos = r.pos;  // (mode:2, k:5) per partition, read when the partition starts
-    if (r.pos + 7ull * parts > r.nbits) return 2;
-    reader_seek(r, r.pos + 7ull * parts);
+    const uint32_t table_pos = r.pos;  // (mode:2, k:5) per partition, read when the partition starts
+    if (r.pos + 7u * parts > r.nbits) return 2;
+    reader_seek(r, r.pos + 7u * parts);
     const bool stateless = p > 0u;
 
     Adapt a;
@@ -260,7 +239,7 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     for (uint32_t i = 0; i < n; ++i) {
         if (i == seg_end) {  // a partition starts
             BitIn t = r;
-            reader_seek(t, table_pos + 7ull * part);
+            reader_seek(t, table_pos + 7u * part);
             mode = get_bits(t, 2);
             k = get_bits(t, 5);
             if (part == 0u && mode != cmode) {
@@ -308,7 +287,7 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
                 u = value;  // Rice value, bin tag 0 (= 0), or the escape's verbatim zigzag value
             }
         }
-        if (r.err && !st) st = 3;
+        if (overrun(r) && !st) st = 3;
         if (!st && (u >> 30)) st = 9;
         if (st) break;
         if (adapt) k = adapt_next(a, u, stateless, dm, lane);
@@ -349,7 +328,7 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     }
     if (st) return st;
     while (r.pos & 7u) {  // zero padding to the byte (ref bit_reader.hpp consume_zero_padding_to_byte)
-        if (get_bits(r, 1) || r.err) return 4;
+        if (get_bits(r, 1) || overrun(r)) return 4;
     }
     return 0;
 }
@@ -377,13 +356,13 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(uint32_t num_blocks, int
     if (blk >= num_blocks) return;
     const uint32_t n = (uint32_t)(frame_off[blk + 1] - frame_off[blk]);
     BitIn r;
-    reader_init(r, payload + byte_off[blk], 8ull * (byte_off[blk + 1] - byte_off[blk]));
+    reader_init(r, payload + byte_off[blk], (uint32_t)(8ull * (byte_off[blk + 1] - byte_off[blk])));
     uint32_t st = 0;
     uint32_t ms = stereo_mode == 1 ? 1u : 0u;
     if (n == 0u || n > (uint32_t)kMaxBlock) st = 1;
     if (!st && channels == 2 && stereo_mode == 2) {  // per-block flag byte (ref lac/decoder.cpp)
         const uint32_t flag = get_bits(r, 8);
-        if (r.err || flag > 1u) st = 1;
+        if (overrun(r) || flag > 1u) st = 1;
         ms = flag;
     }
     if (!st) st = decode_channel_block(r, n, left + frame_off[blk], dm, lane);

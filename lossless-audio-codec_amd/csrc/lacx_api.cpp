@@ -1548,7 +1548,9 @@ int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out) 
     for (uint32_t b = 0; b < nb; ++b) {
         const uint32_t n = be32(lac + 14 + 8ull * b), by = be32(lac + 18 + 8ull * b);
         if (n == 0 || n > (uint32_t)kMaxBlock || (b + 1 < nb && n < 256u)) return decode_fail(LACX_E_INVALID, "[decode-error] invalid block size");
-        if (by == 0) return decode_fail(LACX_E_INVALID, "[decode-error] invalid compressed block size");
+        // (no token is longer than 34 + 32 bits, so a block's two channel bitstreams stay far below 16 MiB; the device
+        // reader's bit positions are 32-bit)
+        if (by == 0 || by > (1u << 24)) return decode_fail(LACX_E_INVALID, "[decode-error] invalid compressed block size");
         frames += n;
         pay += by;
         if (frames > 6912000000ull) return decode_fail(LACX_E_INVALID, "[decode-error] total samples exceed maximum");
