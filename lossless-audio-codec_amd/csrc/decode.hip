@@ -316,7 +316,7 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
                 default: break;
             }
         }
-        if (s < -2147483648ll || s > 2147483647ll) {
+        if ((long long)(int32_t)s != s) {  // the reference rejects a sample that leaves int32 (block/decoder.cpp)
             st = 5;
             break;
         }
