@@ -1,0 +1,72 @@
+// Drop-in mirror of the reference's LAC::Decoder (src/codec/lac/decoder.hpp:10-24): same constructor, decode() and
+// set_thread_count(), implemented over the C ABI of liblacx.so (include/lacx.h: lacx_stream_parse / lacx_decode -- one lane
+// per block on the device).  Failures throw std::runtime_error with the reference's "[decode-error]" prefix
+// (src/codec/lac/decoder.cpp:24-32).  Version-3 streams only (what the encoder writes); the reference's cap of 1 GiB of
+// decoded PCM is not enforced.
+// The header argument is whatever struct the caller uses for it (the reference's FrameHeader, which lives next to its
+// bit reader / writer and is not mirrored here): it only has to have the fields sync, version, channels, stereo_mode,
+// sample_rate, bit_depth and reserved.
+// Kept in an include root of its own (lossless-audio-codec_amd/include_decoder): the recipe that compiles the
+// reference's own tests against the mirror ENCODER (oracle/Makefile, ref-tests) keeps the reference's decoder, whose
+// version-2 and resource-limit tests this decoder does not aim to pass.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include "codec/lac/thread_collector.hpp"
+#include "lacx.h"
+
+namespace LAC {
+
+class Decoder {
+public:
+    explicit Decoder(ThreadCollector* collector = nullptr) : collector(collector), thread_count(0) {}
+
+    void decode(const uint8_t* data, size_t size, std::vector<int32_t>& left, std::vector<int32_t>& right) {
+        decode_impl(data, size, left, right, nullptr);
+    }
+    void decode(const uint8_t* data, size_t size, std::vector<int32_t>& left, std::vector<int32_t>& right, std::nullptr_t) {
+        decode_impl(data, size, left, right, nullptr);
+    }
+    template <class Header>
+    void decode(const uint8_t* data, size_t size, std::vector<int32_t>& left, std::vector<int32_t>& right, Header* out_header) {
+        lacx_stream_info info{};
+        decode_impl(data, size, left, right, &info);
+        if (out_header) {
+            out_header->sync = 0x4C41;
+            out_header->version = 3;
+            out_header->channels = info.channels;
+            out_header->stereo_mode = info.stereo_mode;
+            out_header->sample_rate = info.sample_rate;
+            out_header->bit_depth = info.bit_depth;
+            out_header->reserved = 0;
+        }
+    }
+    void set_thread_count(size_t max_threads) { thread_count = max_threads; }  // no CPU workers here: kept for the callers
+
+private:
+    void decode_impl(const uint8_t* data, size_t size, std::vector<int32_t>& left, std::vector<int32_t>& right,
+                     lacx_stream_info* out_info) {
+        left.clear();
+        right.clear();
+        if (collector) collector->record(std::this_thread::get_id());
+        lacx_stream_info info{};
+        if (lacx_stream_parse(data, size, &info) != LACX_OK) throw std::runtime_error(lacx_decode_last_error());
+        left.resize(info.frames);
+        if (info.channels == 2) right.resize(info.frames);
+        if (lacx_decode(-1, data, size, left.data(), right.empty() ? nullptr : right.data(), info.frames, nullptr) != LACX_OK) {
+            left.clear();
+            right.clear();
+            throw std::runtime_error(lacx_decode_last_error());
+        }
+        if (out_info) *out_info = info;
+    }
+
+    ThreadCollector* collector;
+    size_t thread_count;
+};
+
+}  // namespace LAC

@@ -7,7 +7,16 @@
 #include <vector>
 
 #include "codec/block/encoder.hpp"
+#include "codec/lac/decoder.hpp"
 #include "codec/lac/encoder.hpp"
+
+// a caller's header struct with the reference's field names (src/codec/frame/frame_header.hpp:7-14)
+struct FrameHeader {
+    uint16_t sync = 0;
+    uint8_t version = 0, channels = 0, stereo_mode = 0;
+    uint32_t sample_rate = 0;
+    uint8_t bit_depth = 0, reserved = 0;
+};
 
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
@@ -27,6 +36,14 @@ int main() {
     CHECK(throws<std::invalid_argument>([&] { LAC::Encoder e(12, 2, 22050, 16); e.encode(left, right); }));
     CHECK(throws<std::invalid_argument>([&] { LAC::Encoder e(12, 2, 48000, 20); e.encode(left, right); }));
     CHECK(throws<std::invalid_argument>([&] { LAC::Encoder e(12, 3, 48000, 16); e.encode(left, right); }));
+    // decoder: malformed input is a std::runtime_error before any device is needed (ref tests/test_e2e.cpp:497-545)
+    {
+        LAC::Decoder dec;
+        std::vector<int32_t> ol, orr;
+        std::vector<uint8_t> junk(10, 0);
+        CHECK(throws<std::runtime_error>([&] { dec.decode(junk.data(), junk.size(), ol, orr); }));
+        CHECK(throws<std::runtime_error>([&] { dec.decode(nullptr, 0, ol, orr, nullptr); }));
+    }
     if (lacx_device_count() < 1) {
         CHECK(throws<std::runtime_error>([&] { LAC::Encoder e(12, 2, 48000, 16); e.encode(left, right); }));
         std::printf("mirror api: argument checks %s (no HIP device)\n", fails ? "FAILED" : "ok");
@@ -40,6 +57,25 @@ int main() {
     const std::vector<uint8_t> bytes = enc.encode(left, right, &tc);
     CHECK(bytes.size() > 22 && bytes[0] == 0x4C && bytes[1] == 0x41 && bytes[2] == 3);
     CHECK(tc.snapshot().size() == 1);
+    {   // and back, the way the reference's round-trip helper does it (tests/test_e2e.cpp:110-125)
+        LAC::ThreadCollector dtc;
+        LAC::Decoder dec(&dtc);
+        dec.set_thread_count(2);
+        std::vector<int32_t> ol, orr;
+        FrameHeader hdr;
+        dec.decode(bytes.data(), bytes.size(), ol, orr, &hdr);
+        CHECK(ol == left && orr == right);
+        CHECK(hdr.sync == 0x4C41 && hdr.version == 3 && hdr.channels == 2 && hdr.stereo_mode == 2 && hdr.sample_rate == 48000 &&
+              hdr.bit_depth == 16 && hdr.reserved == 0);
+        CHECK(dtc.snapshot().size() == 1);
+        std::vector<uint8_t> cut(bytes.begin(), bytes.end() - 2);
+        CHECK(throws<std::runtime_error>([&] { dec.decode(cut.data(), cut.size(), ol, orr); }));
+        CHECK(ol.empty() && orr.empty());
+        LAC::Encoder mono(12, 0, 44100, 24);
+        const std::vector<uint8_t> mb = mono.encode(left, {});
+        dec.decode(mb.data(), mb.size(), ol, orr, nullptr);
+        CHECK(ol == left && orr.empty());
+    }
     Block::Encoder benc(12);
     benc.set_zero_run_enabled(false);
     benc.set_partitioning_enabled(false);

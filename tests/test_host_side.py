@@ -122,13 +122,13 @@ def _build_mirror_test():
     exe = os.path.join(build, "mirror_api_test")
     pkgdir = os.path.join(ROOT, "lossless-audio-codec_amd")
     subprocess.check_call(["g++", "-std=c++20", "-O1", "-I", os.path.join(pkgdir, "include"), "-I",
-                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "mirror_api_test.cpp"),
+                           os.path.join(pkgdir, "include_decoder"), "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "mirror_api_test.cpp"),
                            "-L", pkgdir, "-llacx", "-Wl,-rpath," + pkgdir, "-o", exe])
     return exe
 
 
 def test_cpp_mirror_classes_compile_and_validate_arguments(pkg):
-    """LAC::Encoder / Block::Encoder mirrors (reference signatures) over the C ABI."""
+    """LAC::Encoder / Block::Encoder / LAC::Decoder mirrors (reference signatures) over the C ABI."""
     import subprocess
 
     rc = subprocess.call([_build_mirror_test()])
