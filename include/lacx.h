@@ -201,8 +201,8 @@ int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const 
 /* ---- decode: LAC::Decoder::decode, ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
  * src/codec/block/decoder.cpp:64-520.  The product's own check that a .lac gives back the PCM, on the device: one lane
  * per block (the format serialises everything inside a block), all blocks of the stream at once.
- * lacx_stream_parse: host only; the reference reader's structural rules for the header and the block table (version 3;
- * its 1 GiB cap on the decoded PCM is not taken over), LACX_E_INVALID otherwise.
+ * lacx_stream_parse: host only; the reference reader's structural rules for the header and the block table (versions 3
+ * and 2; its 1 GiB cap on the decoded PCM is not taken over), LACX_E_INVALID otherwise.
  * lacx_decode: left / right (right may be null for mono) are caller-owned arrays of `frames` int32 each; a malformed
  * block, a sample outside the bit depth or a residual magnitude the encoder's domain cannot produce (>= 2^30) gives
  * LACX_E_RUNTIME ("[decode-error] block=N ..." in lacx_decode_last_error, the reference throws std::runtime_error with
@@ -214,7 +214,7 @@ typedef struct lacx_stream_info {
     uint8_t channels;
     uint8_t bit_depth;
     uint8_t stereo_mode;
-    uint8_t reserved;
+    uint8_t version; /* 3, or the legacy 2 (no compressed block sizes: decoded by one lane) */
 } lacx_stream_info;
 int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out);
 int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,

@@ -372,6 +372,44 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(uint32_t num_blocks, int
     ms_flag[blk] = (uint8_t)ms;
 }
 
+// The legacy version-2 container carries no compressed block sizes (ref lac/decoder.cpp:209-219): block i starts where
+// block i-1 ended, so ONE lane walks the whole stream.  Kept for completeness of the reader (the encoder has written
+// version 3 only since); status[] is set for the blocks up to and including the first that fails.
+__global__ __launch_bounds__(kDecThreads) void k_decode_serial(uint32_t num_blocks, int channels, int stereo_mode,
+                                                               const uint8_t* __restrict__ payload, uint32_t payload_bits,
+                                                               const unsigned long long* __restrict__ frame_off,
+                                                               int32_t* __restrict__ left, int32_t* __restrict__ right,
+                                                               uint32_t* __restrict__ status, uint8_t* __restrict__ ms_flag) {
+    extern __shared__ __align__(16) unsigned char dec_raw[];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DecMem dm;
+    dm.cols = 1;
+    dm.ring_ = reinterpret_cast<uint32_t*>(dec_raw);
+    dm.hist_ = reinterpret_cast<int32_t*>(dec_raw + 256 * 4);
+    dm.coef_ = reinterpret_cast<int16_t*>(dec_raw + (256 + 32) * 4);
+    BitIn r;
+    reader_init(r, payload, payload_bits);
+    for (uint32_t blk = 0; blk < num_blocks; ++blk) {
+        const uint32_t n = (uint32_t)(frame_off[blk + 1] - frame_off[blk]);
+        uint32_t st = 0, ms = stereo_mode == 1 ? 1u : 0u;
+        if (n == 0u || n > (uint32_t)kMaxBlock) st = 1;
+        if (!st && channels == 2 && stereo_mode == 2) {
+            const uint32_t flag = get_bits(r, 8);
+            if (overrun(r) || flag > 1u) st = 1;
+            ms = flag;
+        }
+        if (!st) st = decode_channel_block(r, n, left + frame_off[blk], dm, 0);
+        if (!st && channels == 2) st = decode_channel_block(r, n, right + frame_off[blk], dm, 0);
+        if (!st && blk + 1u == num_blocks && r.pos != r.nbits) st = 6;  // trailing frame payload
+        status[blk] = st;
+        ms_flag[blk] = (uint8_t)ms;
+        if (st) {
+            for (uint32_t b = blk + 1u; b < num_blocks; ++b) status[b] = 8;  // not reached
+            break;
+        }
+    }
+}
+
 // grid = (blocks, tiles): the samples of block blockIdx.x in tiles of 1024
 __global__ __launch_bounds__(256) void k_ms_inverse(int channels, int bit_depth,
                                                     const unsigned long long* __restrict__ frame_off,
@@ -398,6 +436,12 @@ __global__ __launch_bounds__(256) void k_ms_inverse(int channels, int bit_depth,
     if (bad) atomicMax(&status[blk], 7u);
 }
 
+static void launch_ms_inverse(uint32_t num_blocks, int channels, int bit_depth, const unsigned long long* frame_off,
+                              int32_t* left, int32_t* right, const uint8_t* ms_flag, uint32_t* status, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ms_inverse, dim3(num_blocks, kMaxBlock / 1024), dim3(256), 0, stream, channels, bit_depth, frame_off,
+                       left, right, ms_flag, status);
+}
+
 hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
                          const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,
                          int32_t* right, uint32_t* status, uint8_t* ms_flag, hipStream_t stream) {
@@ -413,8 +457,17 @@ hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_decode, dim3((num_blocks + lanes - 1) / lanes), dim3(kDecThreads), smem, stream, num_blocks, channels,
                        stereo_mode, lanes, payload, byte_off, frame_off, left, right, status, ms_flag);
-    hipLaunchKernelGGL(k_ms_inverse, dim3(num_blocks, kMaxBlock / 1024), dim3(256), 0, stream, channels, bit_depth, frame_off,
-                       left, right, (const uint8_t*)ms_flag, status);
+    launch_ms_inverse(num_blocks, channels, bit_depth, frame_off, left, right, ms_flag, status, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_serial(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
+                                uint32_t payload_bits, const unsigned long long* frame_off, int32_t* left, int32_t* right,
+                                uint32_t* status, uint8_t* ms_flag, hipStream_t stream) {
+    if (num_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode_serial, dim3(1), dim3(kDecThreads), kDecBytesPerCol, stream, num_blocks, channels, stereo_mode,
+                       payload, payload_bits, frame_off, left, right, status, ms_flag);
+    launch_ms_inverse(num_blocks, channels, bit_depth, frame_off, left, right, ms_flag, status, stream);
     return hipGetLastError();
 }
 

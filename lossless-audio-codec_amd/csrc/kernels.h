@@ -96,6 +96,11 @@ hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int
                          const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,
                          int32_t* right, uint32_t* status, uint8_t* ms_flag, hipStream_t stream);
 
+// The legacy version-2 container (no compressed block sizes): one lane walks the whole payload.
+hipError_t launch_decode_serial(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
+                                uint32_t payload_bits, const unsigned long long* frame_off, int32_t* left, int32_t* right,
+                                uint32_t* status, uint8_t* ms_flag, hipStream_t stream);
+
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.
 int debug_read_stamps(unsigned long long* out32);

@@ -1,8 +1,8 @@
 // Drop-in mirror of the reference's LAC::Decoder (src/codec/lac/decoder.hpp:10-24): same constructor, decode() and
 // set_thread_count(), implemented over the C ABI of liblacx.so (include/lacx.h: lacx_stream_parse / lacx_decode -- one lane
 // per block on the device).  Failures throw std::runtime_error with the reference's "[decode-error]" prefix
-// (src/codec/lac/decoder.cpp:24-32).  Version-3 streams only (what the encoder writes); the reference's cap of 1 GiB of
-// decoded PCM is not enforced.
+// (src/codec/lac/decoder.cpp:24-32).  Version-3 streams (what the encoder writes) block-parallel, the legacy version 2 by
+// one lane; the reference's cap of 1 GiB of decoded PCM is not enforced.
 // The header argument is whatever struct the caller uses for it (the reference's FrameHeader, which lives next to its
 // bit reader / writer and is not mirrored here): it only has to have the fields sync, version, channels, stereo_mode,
 // sample_rate, bit_depth and reserved.
@@ -37,7 +37,7 @@ public:
         decode_impl(data, size, left, right, &info);
         if (out_header) {
             out_header->sync = 0x4C41;
-            out_header->version = 3;
+            out_header->version = info.version;
             out_header->channels = info.channels;
             out_header->stereo_mode = info.stereo_mode;
             out_header->sample_rate = info.sample_rate;

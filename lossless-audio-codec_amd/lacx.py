@@ -469,7 +469,7 @@ def wav_parse(wav: bytes):
 
 class StreamInfo(C.Structure):
     _fields_ = [("sample_rate", C.c_uint32), ("blocks", C.c_uint32), ("frames", C.c_uint64), ("channels", C.c_uint8),
-                ("bit_depth", C.c_uint8), ("stereo_mode", C.c_uint8), ("reserved", C.c_uint8)]
+                ("bit_depth", C.c_uint8), ("stereo_mode", C.c_uint8), ("version", C.c_uint8)]
 
 
 def stream_parse(lac: bytes):

@@ -159,7 +159,7 @@ def test_stream_parse_and_decode_without_a_device(pkg):
         (48000, 2, 16, 2, 16421, 2)
     assert pkg.lacx.stream_parse(lac[:-1]) is None          # payload shorter than the table says
     assert pkg.lacx.stream_parse(lac + b"\0") is None       # trailing byte
-    assert pkg.lacx.stream_parse(b"LA\x02" + lac[3:]) is None  # version
+    assert pkg.lacx.stream_parse(b"LA\x04" + lac[3:]) is None  # version (2 and 3 exist)
     assert pkg.lacx.stream_parse(lac[:13]) is None
     bad = bytearray(lac)
     bad[8] = 20  # bit depth

@@ -3,7 +3,7 @@
 In the build container (where /root/reference exists) oracle/Makefile `ref-tests` compiles the reference's
 tests/test_predictors.cpp -- and its whole `lac_tests` executable -- with lossless-audio-codec_amd/include in front of
 the reference's include path and links them with liblacx.so: LAC::Encoder / Block::Encoder are the product's, decoder,
-WAV I/O and bit reader the reference's.  Nothing of the reference is copied; the binaries land in oracle/_ref (ignored
+WAV I/O and bit reader the reference's (a second build of lac_tests also takes the product's LAC::Decoder).  Nothing of the reference is copied; the binaries land in oracle/_ref (ignored
 by git, shipped to the GPU box like oracle/_ref/liblac_ref.so).  On the GPU box the binaries are run: the reference's
 assertions then exercise the HIP path.
 """
@@ -16,13 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 BIN_PRED = os.path.join(ROOT, "oracle", "_ref", "ref_test_predictors_on_mirror")
 BIN_ALL = os.path.join(ROOT, "oracle", "_ref", "ref_lac_tests_on_mirror")
+CODEC = os.path.join(ROOT, "oracle", "_ref", "ref_lac_tests_on_mirror_codec")
 
 
 def test_reference_tests_compile_and_link_against_the_mirror_headers(pkg):
     if not os.path.isdir(os.path.join(REF, "tests")):
         pytest.skip("reference sources absent (GPU box): nothing to compile")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref-tests"], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN_PRED) and os.path.exists(BIN_ALL)
+    assert os.path.exists(BIN_PRED) and os.path.exists(BIN_ALL) and os.path.exists(CODEC)
     rc = subprocess.call([BIN_PRED], stdout=subprocess.DEVNULL)
     assert rc in (0, 77)  # 77: no HIP device here, built and linked only
 
@@ -43,3 +44,14 @@ def test_reference_lac_tests_pass_on_the_hip_path(pkg, tmp_path):
         pytest.skip("oracle/_ref/ref_lac_tests_on_mirror was not built (needs the reference sources)")
     res = subprocess.run([BIN_ALL], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_reference_lac_tests_with_mirror_encoder_and_decoder(pkg, tmp_path):
+    """The same executable with LAC::Decoder replaced too (include_decoder/codec/lac/decoder.hpp over lacx_decode): every
+    whole-stream encode and decode of the reference's tests on the device, its version-2 and malformed-stream cases
+    included."""
+    if not os.path.exists(CODEC):
+        pytest.skip("oracle/_ref/ref_lac_tests_on_mirror_codec not built (needs the reference)")
+    run = subprocess.run([CODEC], capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
