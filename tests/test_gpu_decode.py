@@ -160,3 +160,23 @@ def test_damaged_streams_are_refused(gpu):
             assert l2.size == left.size
         except RuntimeError as err:
             assert "decode-error" in str(err)
+
+
+def test_legacy_version_2_container(gpu):
+    """Version 2 of the container has no compressed block sizes (ref lac/decoder.cpp:100-104, 209-219): the same block
+    payloads back to back behind a table of frame counts.  Rebuilt here from a version-3 stream; one lane walks it."""
+    for frames, ch, bd, sm in ((16384 * 3 + 500, 2, 16, 2), (16384 * 2 + 7, 1, 24, 0), (300, 2, 16, 1)):
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, 48000, seed=77, kind="mixed")
+        v3 = gpu.lacx.Encoder(12, sm, 48000, bd).encode(left, right)
+        info = gpu.lacx.stream_parse(v3)
+        nb = info.blocks
+        table = b"".join(v3[14 + 8 * b:18 + 8 * b] for b in range(nb))
+        v2 = v3[:2] + bytes([2]) + v3[3:14] + table + v3[14 + 8 * nb:]
+        i2 = gpu.lacx.stream_parse(v2)
+        assert i2 is not None and i2.version == 2 and i2.frames == frames and i2.blocks == nb
+        l2, r2, _, _ = gpu.lacx.decode(v2)
+        assert np.array_equal(l2, left) and (right is None or np.array_equal(r2, right))
+        with pytest.raises(RuntimeError, match="decode-error"):
+            gpu.lacx.decode(v2 + b"\0")  # trailing frame payload
+        with pytest.raises(RuntimeError, match="decode-error"):
+            gpu.lacx.decode(v2[:-1])
