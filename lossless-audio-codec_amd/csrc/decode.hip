@@ -111,24 +111,18 @@ __device__ __forceinline__ uint32_t get_bits(BitIn& r, uint32_t n) {  // n <= 32
     refill(r);
     return take(r, n);
 }
-// unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86).  Expects a
-// refilled register; the common case -- the terminator is among the bits at hand -- is a count-leading-ones.
-__device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q) {
-    const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero, so they read as terminators
-    uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
-    if (ones < r.have) {
-        consume(r, ones + 1u);
-        q = ones;
-        return ones <= max_q;
-    }
+// unary: ones terminated by a zero; more than max_q ones is a malformed stream (ref block/decoder.cpp:76-86).
+// The long form: the run of ones goes on beyond the bits at hand -- register by register, with an eye on the end of the
+// block.  (The per-sample loop handles the common case, a terminator among the bits at hand, inline.)
+__device__ bool get_unary_slow(BitIn& r, uint32_t max_q, uint32_t& q) {
     unsigned long long c = 0;
-    for (;;) {  // a long run: register by register, with an eye on the end of the block
+    for (;;) {
         c += r.have;
         consume(r, r.have);
         if (c > (unsigned long long)max_q || r.pos >= r.nbits) return false;
         refill(r);
         const unsigned long long iv = ~r.buf;
-        ones = iv ? (uint32_t)__clzll((long long)iv) : 64u;
+        const uint32_t ones = iv ? (uint32_t)__clzll((long long)iv) : 64u;
         if (ones < r.have) {
             c += ones;
             consume(r, ones + 1u);
@@ -137,6 +131,17 @@ __device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q)
     }
     q = (uint32_t)c;
     return c <= (unsigned long long)max_q;
+}
+// Expects a refilled register.
+__device__ __forceinline__ bool get_unary(BitIn& r, uint32_t max_q, uint32_t& q) {
+    const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero, so they read as terminators
+    const uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
+    if (ones < r.have) {
+        consume(r, ones + 1u);
+        q = ones;
+        return ones <= max_q;
+    }
+    return get_unary_slow(r, max_q, q);
 }
 __device__ __forceinline__ bool get_rice(BitIn& r, uint32_t k, uint32_t& value) {  // k <= 31
     refill(r);
@@ -163,30 +168,35 @@ __device__ __forceinline__ void adapt_reset(Adapt& a) {
     a.count = a.large = a.zero = 0;
     a.lf[0] = a.lf[1] = a.lf[2] = a.zf[0] = a.zf[1] = a.zf[2] = 0;
 }
-// one more sample of magnitude u; returns the parameter for the next one (ref rice.hpp:45-114 / encoder.cpp:72-77)
-__device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool stateless, DecMem& dm, int lane) {
-    a.sum += u;
-    ++a.count;
+// One more sample of magnitude u (if `on`); returns the parameter for the next one (ref rice.hpp:45-114 /
+// encoder.cpp:72-77), or `k` unchanged when `on` is false.  Straight-line for stateless partitions.
+__device__ __forceinline__ uint32_t adapt_next(Adapt& a, uint32_t u, bool on, uint32_t k, bool stateless, DecMem& dm, int lane) {
+    a.sum += on ? u : 0u;
+    a.count += on ? 1u : 0u;
+    const uint32_t cnt = a.count ? a.count : 1u;
     // 32-bit form while the sum allows it (it does for every block of ordinary material)
-    const uint32_t km = (a.sum >> 31) == 0ull ? kmean32((uint32_t)a.sum, a.count) : kmean(a.sum, a.count);
-    if (stateless) return km > 31u ? 31u : km;
-    // drift window: the last 256 magnitudes
-    const uint32_t slot = (a.count - 1u) & 255u;
-    if (a.count > 256u) a.wsum -= dm.ring(slot, lane);
-    dm.ring(slot, lane) = u;
-    a.wsum += u;
-    // micro window: flags of the last 96 samples
-    const uint32_t q = km >= 31u ? 0u : (u >> km);
-    const uint32_t fl = q > 3u ? 1u : 0u, fz = q == 0u ? 1u : 0u;
-    a.large += fl - (a.lf[2] >> 31);
-    a.zero += fz - (a.zf[2] >> 31);
-    a.lf[2] = (a.lf[2] << 1) | (a.lf[1] >> 31);
-    a.lf[1] = (a.lf[1] << 1) | (a.lf[0] >> 31);
-    a.lf[0] = (a.lf[0] << 1) | fl;
-    a.zf[2] = (a.zf[2] << 1) | (a.zf[1] >> 31);
-    a.zf[1] = (a.zf[1] << 1) | (a.zf[0] >> 31);
-    a.zf[0] = (a.zf[0] << 1) | fz;
-    return biased_k<false>(km, a.sum, a.sum - a.wsum, a.large | (a.zero << 16), a.count);
+    const uint32_t km = (a.sum >> 31) == 0ull ? kmean32((uint32_t)a.sum, cnt) : kmean(a.sum, cnt);
+    uint32_t kn = km > 31u ? 31u : km;
+    if (!stateless && on) {
+        // drift window: the last 256 magnitudes
+        const uint32_t slot = (a.count - 1u) & 255u;
+        if (a.count > 256u) a.wsum -= dm.ring(slot, lane);
+        dm.ring(slot, lane) = u;
+        a.wsum += u;
+        // micro window: flags of the last 96 samples
+        const uint32_t q = km >= 31u ? 0u : (u >> km);
+        const uint32_t fl = q > 3u ? 1u : 0u, fz = q == 0u ? 1u : 0u;
+        a.large += fl - (a.lf[2] >> 31);
+        a.zero += fz - (a.zf[2] >> 31);
+        a.lf[2] = (a.lf[2] << 1) | (a.lf[1] >> 31);
+        a.lf[1] = (a.lf[1] << 1) | (a.lf[0] >> 31);
+        a.lf[0] = (a.lf[0] << 1) | fl;
+        a.zf[2] = (a.zf[2] << 1) | (a.zf[1] >> 31);
+        a.zf[1] = (a.zf[1] << 1) | (a.zf[0] >> 31);
+        a.zf[0] = (a.zf[0] << 1) | fz;
+        kn = biased_k<false>(km, a.sum, a.sum - a.wsum, a.large | (a.zero << 16), a.count);
+    }
+    return on ? kn : k;
 }
 
 // One channel block: header, partition table, residual tokens, synthesis, zero padding to the byte
@@ -228,14 +238,28 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
     Adapt a;
     adapt_reset(a);
     uint32_t mode = 0, k = 0, seg_end = 0, part = 0, zeros_left = 0, st = 0;
-    // The last twelve samples and the first twelve coefficients live in registers (a window that moves by one per trip):
-    // a tap is one multiply-add instead of two dependent LDS reads.  Fixed / FIR predictors use hw[0..3].
+    // Every predictor as twelve taps on the last twelve samples, a shift, and a number of warm-up samples that are taken
+    // as they are: fixed orders 1..4 with their binomial taps and no shift, the FIR predictor (3 x1 - x2) >> 2 after two
+    // samples, LPC with its Q15 coefficients (zero beyond the order) from the first sample on -- the window starts as
+    // zeros, which is what "taps that reach before the block start are left out" amounts to.  Window and taps live in
+    // registers; a tap is one multiply-add.
     int32_t hw[12], cw[12];
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
         hw[t] = 0;
-        cw[t] = (type == 2u) ? (int32_t)dm.coef((uint32_t)t, lane) : 0;  // zero beyond the order
+        cw[t] = (type == 2u) ? (int32_t)dm.coef((uint32_t)t, lane) : 0;
     }
+    if (type == 1u) {
+        cw[0] = 3;
+        cw[1] = -1;
+    } else if (type == 0u) {
+        cw[0] = order;                                              // 1 2 3 4
+        cw[1] = order == 2 ? -1 : (order == 3 ? -3 : (order == 4 ? -6 : 0));
+        cw[2] = order == 3 ? 1 : (order == 4 ? 4 : 0);
+        cw[3] = order == 4 ? -1 : 0;
+    }
+    const uint32_t pshift = type == 2u ? 15u : (type == 1u ? 2u : 0u);
+    const uint32_t warm = type == 2u ? 0u : (type == 1u ? 2u : (uint32_t)order);
     for (uint32_t i = 0; i < n; ++i) {
         if (i == seg_end) {  // a partition starts
             BitIn t = r;
@@ -250,76 +274,70 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
             ++part;
             adapt_reset(a);
         }
-        uint32_t u = 0;
-        bool adapt = mode != kModeStatic;  // a static partition keeps the k of its table entry
-        if (zeros_left) {  // inside a zero run: stateful streams adapt on every zero, stateless ones did it at the token
-            --zeros_left;
-            adapt = !stateless;
-        } else {
-            // One token, whatever the grammar: [2-bit tag] [unary quotient] [remainder / sign / 32-bit escape], each part
-            // present or not -- three trips through the bit reader at most, written once for all four modes.
-            const bool is_bin = mode == kModeBin, is_zr = mode == 1u, tagged = is_bin || is_zr;
-            refill(r);
-            const uint32_t tag = tagged ? take(r, 2) : 0u;
-            const bool run_token = is_zr && tag == 1u;
-            const bool has_unary = !tagged || (is_bin ? tag == 3u : tag <= 1u);
-            const uint32_t kk = run_token ? kZeroRunK : k;
-            const uint32_t rem_bits = has_unary ? kk : (is_bin ? ((tag == 1u || tag == 2u) ? 1u : 0u) : (tag == 2u ? 32u : 0u));
-            if (is_zr && tag == 3u) st = 3;
-            uint32_t q = 0;
-            if (has_unary && !get_unary(r, 0xFFFFFFFFu >> kk, q)) st = 3;
-            if (r.have < rem_bits) refill(r);
-            const uint32_t rem = take(r, rem_bits);
-            const uint32_t value = has_unary ? ((q << kk) | rem) : rem;
-            if (is_bin && (tag == 1u || tag == 2u)) {
-                u = zigzag(rem ? -(int32_t)tag : (int32_t)tag);  // +-1, +-2: tag and sign bit
-            } else if (run_token) {
-                const unsigned long long run = (unsigned long long)value + kZeroRunMin;
-                if (run > (unsigned long long)(seg_end - i)) st = 3;
-                zeros_left = (uint32_t)run - 1u;
-                if (stateless) {  // the count jumps by the run, the parameter is recomputed once
-                    a.count += (uint32_t)run;
-                    const uint32_t km = kmean(a.sum, a.count);
-                    k = km > 31u ? 31u : km;
-                    adapt = false;
-                }
+        // One token, whatever the grammar: [2-bit tag] [unary quotient] [remainder / sign / 32-bit escape], each part
+        // present or not, chosen by selects -- the trip has the same few branches for every mode (refills, the long
+        // unary form, the stateful adaptation, the error exit).  A zero run in progress yields its zeros one per trip.
+        const bool in_run = zeros_left != 0u;
+        zeros_left -= in_run ? 1u : 0u;
+        const bool is_bin = mode == kModeBin, is_zr = mode == 1u;
+        const bool tagged = !in_run && (is_bin || is_zr);
+        refill(r);
+        const uint32_t tag = tagged ? (uint32_t)(r.buf >> 62) : 0u;
+        consume(r, tagged ? 2u : 0u);
+        const bool run_token = tagged && is_zr && tag == 1u;
+        const bool has_unary = !in_run && (!tagged || (is_bin ? tag == 3u : tag <= 1u));
+        const uint32_t kk = run_token ? kZeroRunK : k;
+        uint32_t bad = (tagged && is_zr && tag == 3u) ? 3u : 0u;
+        uint32_t q = 0;
+        {
+            const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero: they read as terminators
+            const uint32_t ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
+            if (has_unary && ones >= r.have) {  // the run of ones goes on beyond the bits at hand (rare)
+                if (!get_unary_slow(r, 0xFFFFFFFFu >> kk, q)) bad = 3u;
             } else {
-                u = value;  // Rice value, bin tag 0 (= 0), or the escape's verbatim zigzag value
+                q = has_unary ? ones : 0u;
+                consume(r, has_unary ? ones + 1u : 0u);
+            }
+            if (q > (0xFFFFFFFFu >> kk)) bad = 3u;
+        }
+        const uint32_t rem_bits =
+            in_run ? 0u : (has_unary ? kk : (is_bin ? ((tag == 1u || tag == 2u) ? 1u : 0u) : ((is_zr && tag == 2u) ? 32u : 0u)));
+        if (r.have < rem_bits) refill(r);
+        const uint32_t rem = take(r, rem_bits);
+        const uint32_t value = has_unary ? ((q << kk) | rem) : rem;
+        const bool small_bin = tagged && is_bin && (tag == 1u || tag == 2u);  // +-1, +-2: tag and sign bit
+        const uint32_t u = small_bin ? zigzag(rem ? -(int32_t)tag : (int32_t)tag) : ((run_token || in_run) ? 0u : value);
+        bool adapt = mode != kModeStatic;  // a static partition keeps the k of its table entry
+        if (in_run) adapt = !stateless;    // stateful streams adapt on every zero, stateless ones did it at the token
+        if (run_token) {
+            const unsigned long long run = (unsigned long long)value + kZeroRunMin;
+            if (run > (unsigned long long)(seg_end - i)) bad = 3u;
+            zeros_left = (uint32_t)run - 1u;
+            if (stateless) {  // the count jumps by the run, the parameter is recomputed once
+                a.count += (uint32_t)run;
+                const uint32_t km = kmean(a.sum, a.count);
+                k = km > 31u ? 31u : km;
+                adapt = false;
             }
         }
-        if (overrun(r) && !st) st = 3;
-        if (!st && (u >> 30)) st = 9;
-        if (st) break;
-        if (adapt) k = adapt_next(a, u, stateless, dm, lane);
-        // synthesis
-        long long s = unzigzag(u);
-        const long long h1 = hw[0], h2 = hw[1], h3 = hw[2], h4 = hw[3];
-        if (type == 2u) {
-            // hw[t-1] = sample i - t; before the first sample the window holds zeros, which is what "taps that reach
-            // before the block start are left out" amounts to.  Orders above 12 (valid streams, none from this encoder)
-            // take their remaining taps from the history in LDS.
-            long long acc = 0;
+        if (overrun(r)) bad = 3u;
+        if (!bad && (u >> 30)) bad = 9u;
+        // synthesis: twelve taps (orders above 12 -- valid streams, none from this encoder -- add theirs from LDS)
+        long long acc = 0;
 #pragma unroll
-            for (int t = 0; t < 12; ++t) acc += (long long)cw[t] * (long long)hw[t];
+        for (int t = 0; t < 12; ++t) acc += (long long)cw[t] * (long long)hw[t];
+        if (type == 2u && order > 12) {
             const int taps = order < (int)i ? order : (int)i;
             for (int t = 13; t <= taps; ++t)
                 acc += (long long)dm.coef((uint32_t)t - 1u, lane) * (long long)dm.hist((i - (uint32_t)t) & 31u, lane);
-            s += acc >> 15;
-        } else if (type == 1u) {
-            if (i >= 2u) s += (3 * h1 - h2) >> 2;
-        } else if (i >= (uint32_t)order) {
-            switch (order) {
-                case 1: s += h1; break;
-                case 2: s += 2 * h1 - h2; break;
-                case 3: s += 3 * h1 - 3 * h2 + h3; break;
-                case 4: s += 4 * h1 - 6 * h2 + 4 * h3 - h4; break;
-                default: break;
-            }
         }
-        if ((long long)(int32_t)s != s) {  // the reference rejects a sample that leaves int32 (block/decoder.cpp)
-            st = 5;
+        const long long s = (long long)unzigzag(u) + (i >= warm ? (acc >> pshift) : 0ll);
+        if ((long long)(int32_t)s != s && !bad) bad = 5u;  // the reference rejects a sample that leaves int32
+        if (bad) {
+            st = bad;
             break;
         }
+        k = adapt_next(a, u, adapt, k, stateless, dm, lane);
         out[i] = (int32_t)s;
         if (type == 2u && order > 12) dm.hist(i & 31u, lane) = (int32_t)s;
 #pragma unroll
