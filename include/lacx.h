@@ -20,8 +20,11 @@
  *   lacx_assemble          <- the block loop + block table concat of LAC::Encoder::encode, split so that
  *                             contiguous block ranges can be encoded by different GPUs/processes
  *                                                            ref lac/encoder.cpp:252-263, 445-465
+ *   lacx_stream_parse /
+ *   lacx_decode            <- LAC::Decoder::decode          ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
+ *                                                            src/codec/block/decoder.cpp:64-520
  *
- * All analysis runs in hand-written HIP kernels on a gfx950 device; there is no CPU fallback: every
+ * All analysis (and the decode) runs in hand-written HIP kernels on a gfx950 device; there is no CPU fallback: every
  * call that needs the device fails with LACX_E_DEVICE when none is usable.
  */
 #ifndef LACX_H
