@@ -48,6 +48,19 @@ CFG4_SECONDS = 7200
 METRIC = "encode Msamples/s at 1/2/4/8 MI355X; byte-identical .lac vs CPU ref"
 
 
+KERNEL_SOURCES = ("kernels.hip", "analyze_core.h", "emit_core.h")  # what the committed counter passes were measured on
+
+
+def kernel_source_sha256() -> str:
+    """sha256 over the sources of the dominant kernel, in a fixed order: profiles/valu.json and profiles/traffic.json carry
+    the value they were measured at (scripts/summarize_counters.py), and the bench line only quotes them for these sources."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lossless-audio-codec_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-weak-line", action="store_true", help="N>1: skip the additional 10 min per GPU measurement")
     ap.add_argument("--no-end-to-end", action="store_true", help="N=1: skip the host WAV -> host .lac measurement")
     ap.add_argument("--no-decode-check", action="store_true", help="N=1: skip decoding the GPU's .lac on the device")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="N=1: skip the verified extra workloads (configs[2] at full size, white noise, configs[4] as one job)")
     ap.add_argument("--analysis-only", action="store_true", help="time the device analysis alone (diagnostic)")
     ap.add_argument("--host-emit", action="store_true", help="keep the bit emit on the host (north_star layout)")
     ap.add_argument("--planar", action="store_true", help="planar int32 device input (the reference API layout) instead of interleaved int16")
@@ -146,15 +161,17 @@ def worker(args) -> int:
     lacx, synth = pkg.lacx, pkg.synth
     digests = load_digests()
 
-    host_cores = os.cpu_count() or 1
+    # cores this process may run on (the box confines a one-GPU lease to its CPU share), not the host's total
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    host_cores_total = os.cpu_count() or host_cores
     # host threads of this rank: the box's CPU share per GPU (16), overridable for tuning
     share = max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
     emit_threads = int(os.environ.get("LACX_EMIT_THREADS", "0")) or min(16, share)
-    enc = lacx.Encoder(12, STEREO_MODE, sample_rate, bit_depth, device=device)
+    bit_depth0, sample_rate0 = bit_depth, sample_rate
+    enc = enc0 = lacx.Encoder(12, STEREO_MODE, sample_rate, bit_depth, device=device)
     enc.set_thread_count(emit_threads)
     enc.set_host_emit(args.host_emit)
     stream = torch.cuda.current_stream().cuda_stream
-    layout = lacx.PCM_INTERLEAVED_I16 if bit_depth == 16 else lacx.PCM_INTERLEAVED_I24
     interleaved = not (args.planar or args.host_emit or args.analysis_only)
 
     def sync():
@@ -169,14 +186,17 @@ def worker(args) -> int:
         dist.all_reduce(t)
         return int(t.item())
 
-    def measure(total_frames: int, tag: str):
-        """Times `steps` encodes of this rank's block range of a `total_frames` stream; contract timing."""
+    def measure(total_frames: int, tag: str, spec=None):
+        """Times `steps` encodes of this rank's block range of a `total_frames` stream; contract timing.
+        spec: (encoder, bit_depth, sample_rate, kind, seed) of a stream other than the command line's."""
+        enc, bit_depth, sample_rate, kind, seed = spec if spec else (enc0, bit_depth0, sample_rate0, args.kind, 2026)
+        layout = lacx.PCM_INTERLEAVED_I16 if bit_depth == 16 else lacx.PCM_INTERLEAVED_I24
         total_blocks = (total_frames + BLOCK - 1) // BLOCK
         b0 = rank * total_blocks // world
         b1 = (rank + 1) * total_blocks // world
         f0 = b0 * BLOCK
         frames = min(b1 * BLOCK, total_frames) - f0
-        left, right = synth.synth_pcm(frames, 2, bit_depth, sample_rate, seed=2026, kind=args.kind, start=f0)
+        left, right = synth.synth_pcm(frames, 2, bit_depth, sample_rate, seed=seed, kind=kind, start=f0)
         if interleaved:  # the WAV data-chunk layout: 2 (3) bytes per sample in HBM
             inter = synth.interleave(left, right, bit_depth)
             d_pcm = torch.from_numpy(inter.view(np.int16) if bit_depth == 16 else inter).cuda()
@@ -257,8 +277,12 @@ def worker(args) -> int:
                     elapsed=elapsed, last=last, rec=rec, timing=tm, left=left, right=right,
                     value=total_frames * 2 * args.steps / elapsed / 1e6, ms_per_step=elapsed / args.steps * 1e3)
 
-    def lac_of(payload_bytes: bytes, table) -> bytes:
-        return lacx.assemble(sample_rate, bit_depth, STEREO_MODE, 2, [(payload_bytes, table)])
+    def lac_of(payload_bytes: bytes, table, sr=sample_rate, bd=bit_depth, sm=STEREO_MODE, ch=2) -> bytes:
+        return lacx.assemble(sr, bd, sm, ch, [(payload_bytes, table)])
+
+    def digest_matches(lac: bytes, name: str) -> bool:
+        d = digests.get(name)
+        return d is not None and len(lac) == d["lac_bytes"] and hashlib.sha256(lac).hexdigest() == d["lac_sha256"]
 
     # ---- the headline measurement ----------------------------------------------------------------
     workload = args.workload
@@ -297,12 +321,29 @@ def worker(args) -> int:
     ranks_seen = all_sum(1)
 
     # ---- N > 1: the weak line (10 min per GPU) -----------------------------------------------------
-    weak = None
+    weak = weak96 = None
     if world > 1 and workload == "cfg4" and not args.no_weak_line and not args.seconds:
+        def rank0_matches(w, name, sr, bd):  # rank 0's range of the weak stream IS the 10 min stream the digest was minted on
+            if rank != 0 or w["last"] is None:
+                return None
+            return digest_matches(lac_of(w["last"][0].tobytes(), np.array(w["last"][1], dtype=np.uint32), sr, bd), name)
+
         w = measure(CFG2_SECONDS * sample_rate * world, "weak")
         weak = {"value": round(w["value"], 3), "unit": "Msamples/s", "ms_per_step": round(w["ms_per_step"], 3),
-                "scaling": "weak", "workload": "10 min per GPU (BASELINE configs[1] material), rank r = r-th contiguous block range"}
+                "scaling": "weak", "workload": "10 min per GPU (BASELINE configs[1] material), rank r = r-th contiguous block range",
+                "rank0_matches_golden_digest": rank0_matches(w, "cfg2_10min_st16_48k_auto", sample_rate, bit_depth) if std_format else None}
         del w
+        # north_star: "throughput on synthetic 48 kHz / 96 kHz PCM reported at 1, 2, 4 and 8 GPUs" -- the 96 kHz line:
+        # 10 min of 24-bit 96 kHz per GPU (BASELINE configs[2] material), same contiguous block-range split
+        enc96 = lacx.Encoder(12, STEREO_MODE, 96000, 24, device=device)
+        w = measure(CFG2_SECONDS * 96000 * world, "weak96", (enc96, 24, 96000, "mixed", 7))
+        weak96 = {"value": round(w["value"], 3), "unit": "Msamples/s", "ms_per_step": round(w["ms_per_step"], 3),
+                  "scaling": "weak", "workload": "10 min of stereo 24-bit 96 kHz per GPU (BASELINE configs[2] material), rank r = r-th contiguous block range",
+                  "rank0_matches_golden_digest": rank0_matches(w, "cfg3_10min_st24_96k_mixed", 96000, 24)}
+        del w, enc96
+        for line in (weak, weak96):
+            if rank == 0 and line["rank0_matches_golden_digest"] is False:
+                raise SystemExit("bench.py: rank 0's weak-line .lac does not match the golden digest -- refusing to report a number")
 
     if rank != 0:
         if world > 1:
@@ -330,19 +371,32 @@ def worker(args) -> int:
     algo_bytes = (frames * 2 * (bit_depth // 8) + tm.full_slots * 296 + fused_payload) / n_launch
     achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     default_run = (workload == "cfg2" and not args.seconds and world == 1 and not args.host_emit and std_format)
+    # SURVEY 8(d)'s own byte definition (PCM at its source depth + plan records, nothing else), beside the figure that also
+    # counts the bitstream bytes the fused emit writes
+    survey_bytes = (frames * 2 * (bit_depth // 8) + tm.full_slots * 296) / n_launch
+    achieved_survey = survey_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    # Counter-derived fields come from committed rocprofv3 --pmc passes (the profiler cannot run inside the bench); they are
+    # quoted only when they were measured on THESE kernel sources (scripts/summarize_counters.py records the hash).
+    src_hash = kernel_source_sha256()
+    stale_profiles = False
     traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench itself)
+    try:  # HBM bytes per launch from the committed PMC passes
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
         if default_run and abs(n_launch - float(tj.get("launches_per_step", 2))) < 1e-9:
-            traffic = tj["traffic_bytes_per_launch"]
+            if tj.get("kernel_source_sha256") == src_hash:
+                traffic = tj["traffic_bytes_per_launch"]
+            else:
+                stale_profiles = True
     except Exception:
         traffic = None
     valu = None
     try:  # VALU-side roofline: wave-instruction counts from the committed SQ counter passes (profiles/valu.json)
         with open(os.path.join(ROOT, "profiles", "valu.json")) as f:
             vj = json.load(f)
-        if default_run:
+        if default_run and vj.get("kernel_source_sha256") != src_hash:
+            stale_profiles = True
+        elif default_run:
             insts = float(vj["valu_wave_insts_per_step"]) / n_launch
             valu = {
                 "wave_insts_per_launch": int(insts),
@@ -361,7 +415,14 @@ def worker(args) -> int:
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "frac_survey_bytes": round(achieved_survey / HBM_PEAK_GBS, 6),
+        "achieved_survey_bytes": round(achieved_survey, 3),
+        "algorithmic_bytes_survey": int(survey_bytes),
+        "bytes_definition": "achieved/frac: PCM at source depth + plan records + the bitstream bytes the fused emit writes (DESIGN.md 5); "
+                            "*_survey_bytes: SURVEY 8(d) as written (PCM + plan records only)",
         "traffic": traffic,
+        "stale_profiles": stale_profiles,
+        "kernel_source_sha256": src_hash[:16],
         "kernel_ms": round(kernel_s * 1e3, 4),
         "kernel_exec_ms": round(exec_s * 1e3, 4) if exec_s > 0 else None,
         "launches_per_step": n_launch,
@@ -406,7 +467,7 @@ def worker(args) -> int:
             dt = time.perf_counter() - t1
             return data, {
                 "value": round(n_cpu * 2 / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "host_cores": host_cores,
-                "kind": kind,
+                "host_cores_total": host_cores_total, "kind": kind,
                 "sample": f"first {n_cpu} frames ({n_cpu / sample_rate:.0f} s) of the same stereo {bit_depth}-bit {sample_rate} Hz stream, "
                           f"{dt:.2f} s wall, {len(data)} B .lac",
             }
@@ -418,7 +479,7 @@ def worker(args) -> int:
             if not identical:
                 raise SystemExit("bench.py: the GPU .lac differs from the CPU encoder's -- refusing to report a number")
         if host_cores > emit_threads:
-            data2, cpu_all = cpu_leg(host_cores)  # every host core of the box
+            data2, cpu_all = cpu_leg(host_cores)  # every core this process is allowed to run on (sched_getaffinity)
             if data2 != data:
                 raise SystemExit("bench.py: the CPU encoder's output depends on its thread count")
             del data2
@@ -465,6 +526,83 @@ def worker(args) -> int:
         if not same_pcm:
             raise SystemExit("bench.py: the GPU .lac does not decode back to the PCM -- refusing to report a number")
 
+    # ---- N = 1: the other single-GPU BASELINE configs, each verified against its reference-minted digest -----------
+    # Outside the headline loop (never part of `value`): BASELINE configs[2] at its stated size (10 min stereo 24-bit 96 kHz,
+    # mixed material), one minute of white noise 16/48 (the hardest material: every block "uncertain", about five exactly
+    # costed candidates per slot) and BASELINE configs[4] (the 16 combinations {mono, stereo} x {16, 24 bit} x {44.1, 48,
+    # 96, 192 kHz}, 60 s each) as ONE job.  A step = the whole job with its PCM resident in HBM in WAV layout, result in
+    # pinned host memory; every .lac of the last step is compared with the golden digest minted from the reference
+    # (tests/golden/make_golden.py) and nothing is printed on a mismatch.
+    other = None
+    if world == 1 and default_run and not args.no_other_workloads and not args.analysis_only:
+        del left, right
+        main["left"] = main["right"] = None
+        other = []
+
+        def timed_job(name, specs, steps=5, warmup=1):
+            # specs: (digest name, frames, channels, bit_depth, rate, stereo_mode, kind, stereo family, seed)
+            jobs = []
+            for dname, frames_j, ch, bd, sr, sm, kind, st, seed in specs:
+                l_, r_ = synth.synth_pcm(frames_j, ch, bd, sr, seed=seed, kind=kind, stereo=st)
+                inter = synth.interleave(l_, r_, bd)
+                del l_, r_
+                d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+                del inter
+                jobs.append(dict(name=dname, frames=frames_j, ch=ch, bd=bd, sr=sr, sm=sm, d=d,
+                                 layout=lacx.PCM_INTERLEAVED_I16 if bd == 16 else lacx.PCM_INTERLEAVED_I24))
+            torch.cuda.synchronize()
+            run = make_runner(jobs)
+            for _ in range(warmup):
+                run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                res, kernel_ms = run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / steps
+            ok = True
+            for j, (pay, tab) in zip(jobs, res):
+                lac = lac_of(pay.tobytes(), np.array(tab, dtype=np.uint32), j["sr"], j["bd"], j["sm"], j["ch"])
+                ok = ok and digest_matches(lac, j["name"])
+            samples = sum(j["frames"] * j["ch"] for j in jobs)
+            if not ok:
+                raise SystemExit(f"bench.py: {name}: a .lac does not match the reference's golden digest -- refusing to report a number")
+            other.append({"workload": name, "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
+                          "ms_per_step": round(dt * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "streams": len(jobs),
+                          "samples": samples, "steps": steps, "matches_golden_digest": True})
+            del jobs
+
+        def make_runner(jobs):
+            if len(jobs) > 1 and hasattr(lacx, "BatchEncoder"):
+                be = lacx.BatchEncoder([(j["sr"], j["bd"], j["sm"]) for j in jobs], device=device)
+
+                def run_batch():
+                    res = be.encode_device([(j["d"].data_ptr(), j["layout"], j["ch"], j["frames"]) for j in jobs], stream)
+                    return res, be.timing().full_ms
+                return run_batch
+            encs = [lacx.Encoder(12, j["sm"], j["sr"], j["bd"], device=device) for j in jobs]
+
+            def run_each():  # every stream enqueued before the first result is collected
+                for e_, j in zip(encs, jobs):
+                    e_.encode_shard_pcm_device_begin(j["d"].data_ptr(), j["layout"], j["ch"], j["frames"], stream)
+                res = [e_.encode_shard_end() for e_ in encs]
+                return res, sum(e_.timing().full_ms for e_ in encs)
+            return run_each
+
+        timed_job("BASELINE configs[2]: 10 min synthetic stereo 24-bit 96 kHz (mixed material), partitioning + zero-run on",
+                  [("cfg3_10min_st24_96k_mixed", 57_600_000, 2, 24, 96000, 2, "mixed", "wide", 7)])
+        timed_job("white noise: 60 s synthetic stereo 16-bit 48 kHz, independent channels (every block uncertain)",
+                  [("noise_60s_st16_48k", 2_880_000, 2, 16, 48000, 2, "noise", "independent", 3)])
+        cfg5 = []
+        for ch in (1, 2):
+            for bd in (16, 24):
+                for sr in (44100, 48000, 96000, 192000):
+                    i = len(cfg5)
+                    cfg5.append((f"cfg5_{i:02d}_{'st' if ch == 2 else 'mono'}{bd}_{sr}", 60 * sr, ch, bd, sr, 2 if ch == 2 else 0,
+                                 "mixed" if i & 1 else "music", "wide", 500 + i))
+        timed_job("BASELINE configs[4]: mixed corpus as one job -- {mono, stereo} x {16, 24 bit} x {44.1, 48, 96, 192 kHz}, 60 s each, "
+                  "16 streams, per-block predictor + stereo auto-select", cfg5)
+
     out = {
         "metric": METRIC,
         "value": round(main["value"], 3),
@@ -497,6 +635,7 @@ def worker(args) -> int:
         "rehearsal_shared_gpu": bool(rehearse) if world > 1 else False,
         "byte_identical_shards": (f"{shard_ok}/{world}" if shard_ok is not None else None),
         "weak_10min_per_gpu": weak,
+        "weak_10min_per_gpu_24bit_96k": weak96,
         "breakdown_ms": {
             "device_analysis": round(mean("analysis_ms"), 3),
             "k_ingest_levinson": round(mean("ingest_ms"), 3),
@@ -509,9 +648,10 @@ def worker(args) -> int:
         "device_analysis_msamples_s": round(frames * 2 / (max(mean("analysis_ms"), 1e-9) / 1e3) / 1e6, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "cpu_baseline_all_cores": cpu_all,
+        "cpu_baseline_all_allowed_cores": cpu_all,
         "end_to_end": e2e,
         "decode_check": decode_check,
+        "other_workloads": other,
         "byte_identical_to_cpu_baseline": identical,
         "matches_golden_digest": digest_ok,
     }

@@ -224,7 +224,7 @@ struct Smem {
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
-    uint32_t lbacc[11][3];         // per candidate: block sums of Thread::lb_g / lb_aux / lb_ends (pruning bound)
+    uint32_t lbacc[11][3];         // per candidate: block sums behind the pruning bound (pass1_bounds): sum of bit_width(u) + 1; zeros | fours << 16; run ends
     uint32_t has4[2];              // current candidate has a run of >= 4 zero residuals (zero-run mode possible)
     uint64_t wtotP[16];  // per-wave totals used by the block scans
     int32_t wtotZ[16];
@@ -257,10 +257,6 @@ struct Thread {
     uint32_t cs[G::LV];  // bit-sliced per-plane counts of this chunk
     unsigned long long crice, cbin, czr;  // chunk partial costs
     uint32_t chasrun;
-    uint32_t lb_g;    // sum over the chunk of bit_width(u)+1 (per-sample floor of any Rice code)
-    uint32_t lb_aux;  // count(u == 0) | count(u == 4) << 16   (host form of the bound partials)
-    uint32_t lb_ends; // zero runs that end inside the chunk (a zero followed by a non-zero); the wave's count on the device
-    uint32_t lb_wz, lb_wf;  // device form: the wave's counts of u == 0 (incl. positions beyond the slot) and u == 4
     uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
 };
 
@@ -456,7 +452,7 @@ LACX_HD void plane_counts(const uint32_t* u, uint32_t* cs) {
 // Fixed differences are taken in wrapping 32-bit arithmetic: the true values fit int32 for
 // |x| <= 2^24, so the low 32 bits equal the reference's int64 results.
 // ---------------------------------------------------------------------------------------------
-// Part 1: the chunk's zigzag residual into registers, and the partial sums of the pruning bound.
+// Part 1: the chunk's zigzag residual into registers.
 template <class G, class M>
 LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u /* CH */) {
     // x[a-12 .. a+CH): element `el` of chunk tid+co sits at row el, column tid+co of the transposed
@@ -527,48 +523,6 @@ LACX_HD void phase_r_residual(Thread<G>& th, const M& sh, int cand, uint32_t* u 
         else if (ord <= 10) lpc(std::integral_constant<int, 10>{});
         else lpc(std::integral_constant<int, 12>{});
     }
-    // bound partials: sum of bit_width(u) + 1 = 33 per sample minus the leading-zero counts; zeros and fours.
-    // Positions beyond the slot hold u = 0: they are summed like the others (no per-sample predicate) and taken
-    // out afterwards: each adds 32 to the leading-zero sum and 1 to the zero count.
-#if defined(__HIP_DEVICE_COMPILE__)
-    // Device form: the zero and four counts are only needed per block, so they are taken per wave from ballots -- one
-    // compare per sample, the population counts and their sum run on the scalar unit -- and clz(u) = clz(u | 1) + [u == 0]
-    // needs no special case for zero.  th.lb_g then lacks the wave's zero count, which the driver subtracts once per
-    // wave (lb_wz); lb_wz / lb_wf are wave-uniform and count the positions beyond the slot as zeros.
-    {
-        uint32_t c1sum = 0, wz = 0, wf = 0, we = 0;
-        unsigned long long zprev = 0;  // lanes whose previous sample was zero
-#pragma unroll
-        for (int i = 0; i < G::CH; ++i) {
-            c1sum += (uint32_t)__builtin_clz(u[i] | 1u);
-            const unsigned long long zcur = __ballot(u[i] == 0u);
-            wz += (uint32_t)__popcll(zcur);
-            we += (uint32_t)__popcll(zprev & ~zcur);  // scalar unit: a zero run ends here (positions beyond the slot are zeros: no end)
-            zprev = zcur;
-            wf += (uint32_t)__popcll(__ballot(u[i] == 4u));
-        }
-        const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
-        th.lb_g = 33u * (uint32_t)th.cnt + 32u * beyond - c1sum;
-        th.lb_wz = wz;
-        th.lb_wf = wf;
-        th.lb_ends = we;
-        th.lb_aux = 0;
-        return;
-    }
-#endif
-    uint32_t clzsum = 0, nzero = 0, nfour = 0, ends = 0;
-#pragma unroll
-    for (int i = 0; i < G::CH; ++i) {
-        clzsum += (uint32_t)clz32(u[i]);
-        nzero += 1u - (u[i] < 1u ? u[i] : 1u);           // 1 when u == 0
-        const uint32_t x4 = u[i] ^ 4u;
-        nfour += 1u - (x4 < 1u ? x4 : 1u);               // 1 when u == 4
-        if (i > 0 && u[i - 1] == 0u && u[i] != 0u) ++ends;
-    }
-    const uint32_t beyond = (uint32_t)(G::CH - th.cnt);
-    th.lb_g = 33u * (uint32_t)th.cnt - (clzsum - 32u * beyond);
-    th.lb_aux = (nzero - beyond) + (nfour << 16);
-    th.lb_ends = ends;
 }
 
 // Part 2 (only for candidates that survive the pruning): the residual into LDS, the chunk sum, the last non-zero
@@ -593,6 +547,166 @@ LACX_HD void phase_r(Thread<G>& th, M& sh, int cand) {
     uint32_t u[G::CH];
     phase_r_residual(th, sh, cand, u);
     phase_r_store(th, sh, u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 1: the pruning-bound partials of ALL eleven candidates in one walk over the chunk.
+// The bound (candidate_lower_bound) needs four block sums per candidate: sum of bit_width(u) + 1, the zeros, the
+// fours (u == 4) and the zero runs that end inside a chunk.  None of them needs the zigzag value itself:
+//   bit_width(u) = 1 + bit_width(r ^ (r >> 31)) for r != 0, so clz(u | 1) + 1 = lead_m(r) := the number of leading bits
+//   of r that equal its sign bit, capped at 32 (ONE instruction, v_ffbh_i32; r = 0 and r = -1 give 32);
+//   u == 0 <=> r == 0 and u == 4 <=> r == 2.
+// The sample window is loaded once for all candidates, the five fixed orders are nested differences (order K + 1 is
+// the first difference of order K: four subtractions per sample for all of them instead of ten multiply-adds), and
+// nothing is stored.  Per sample and candidate that leaves lead_m + min + add and a 2-bit code (min + shift-add) from
+// which zeros, fours and run ends are counted once per chunk, against the residual + zigzag + clz + three compares and
+// seven scalar instructions of a candidate-by-candidate walk with wave ballots (ref block/encoder.cpp:362-407 computes
+// every residual in full and costs it exactly).
+// Positions beyond the slot count as r = 0 (a zero, no run end); the driver takes them out again.
+// ---------------------------------------------------------------------------------------------
+LACX_HD uint32_t lead_m(int32_t r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t f;  // v_ffbh_i32: position of the first bit that differs from the sign bit, -1 when none does
+    asm("v_ffbh_i32 %0, %1" : "=v"(f) : "v"(r));
+    return f < 32u ? f : 32u;
+#else
+    const uint32_t v = (uint32_t)(r ^ (r >> 31));
+    return v ? (uint32_t)__builtin_clz(v) : 32u;
+#endif
+}
+
+struct BoundPartials {
+    uint32_t msum;  // this thread: sum over the CH positions of lead_m(r)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Device: two bits per position, first sample in the highest of the CH pairs: min(uint32(r), 3), i.e. 0 for a zero
+    // and 2 for r == 2 (u == 4) -- one min and one shift-add per sample; zeros, fours and run ends are counted from it
+    // once per chunk (bound_counts).  (Counting them per sample from wave ballots -- two compares and seven scalar
+    // instructions per sample and candidate -- made the scalar unit the bottleneck of this pass.)
+    uint32_t code;
+#else
+    // host simulator: this thread's counts
+    uint32_t nz;    // r == 0 (incl. the positions beyond the slot)
+    uint32_t n4;    // r == 2, i.e. u == 4
+    uint32_t ends;  // a zero followed by a non-zero inside a chunk
+    uint32_t zprev;
+#endif
+};
+
+LACX_HD void bound_init(BoundPartials& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    b.msum = b.code = 0;
+#else
+    b.msum = b.nz = b.n4 = b.ends = b.zprev = 0;
+#endif
+}
+
+LACX_HD void bound_add(BoundPartials& b, int32_t r) {
+    b.msum += lead_m(r);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t v = (uint32_t)r;
+    b.code = (b.code << 2) + (v < 3u ? v : 3u);
+#else
+    const uint32_t z = r == 0 ? 1u : 0u;
+    b.nz += z;
+    b.ends += (b.zprev && !z) ? 1u : 0u;
+    b.zprev = z;
+    b.n4 += r == 2 ? 1u : 0u;
+#endif
+}
+
+// This thread's zeros | fours << 11 | run ends << 22 over its CH positions (each field leaves room for the sum over a
+// wave: at most 64 * 16 = 1024 zeros or fours and 64 * 8 run ends).
+template <int CH>
+LACX_HD uint32_t bound_counts(const BoundPartials& b) {
+    static_assert(CH <= 16, "two bits per position in one word");
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr uint32_t kLow = CH == 16 ? 0x55555555u : ((1u << (2 * (CH & 15))) - 1u) & 0x55555555u;  // low bit of every pair in use
+    const uint32_t lo = b.code & kLow, hi = (b.code >> 1) & kLow;
+    const uint32_t zero = ~(lo | hi) & kLow;                  // pair == 0
+    const uint32_t four = hi & ~lo;                           // pair == 2
+    // pair p = position CH - 1 - p: a zero (pair p) followed by a non-zero (pair p - 1); the last position ends nothing
+    const uint32_t ends = zero & ~(zero << 2) & ~1u;
+    return (uint32_t)__builtin_popcount(zero) | ((uint32_t)__builtin_popcount(four) << 11) |
+           ((uint32_t)__builtin_popcount(ends) << 22);
+#else
+    return b.nz | (b.n4 << 11) | (b.ends << 22);
+#endif
+}
+
+// FULL: every position of every chunk lies inside the slot (n == MAXN, block-uniform): no per-sample masking.
+// lpc_off: the LPC candidates are switched off (diagnostic ablation).  out[c] of an unavailable LPC candidate is zeroed.
+template <class G, bool FULL, class M>
+LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundPartials* out /* 11 */) {
+    int32_t xh[G::CH + 12];
+#pragma unroll
+    for (int i = 0; i < G::CH + 12; ++i) {  // the window, as in phase_r_residual
+        const int d = i - 12;
+        const int co = (d >= 0) ? d / G::CH : -((-d + G::CH - 1) / G::CH);
+        const int el = d - co * G::CH;
+        const int tt = th.tid + co;
+        const int32_t* col = &sh.xp.x[tt < 0 ? 0 : tt];
+        xh[i] = (tt >= 0) ? col[el * G::T] : 0;
+    }
+    const int32_t* x = xh + 12;
+    const bool first = th.a == 0;  // the slot's first chunk: warm-up samples are taken raw (ref block/encoder.cpp:265-309)
+    auto live = [&](int i, int32_t r) { return FULL ? r : ((i < th.cnt) ? r : 0); };
+    {
+        // fixed orders 0..4 and the FIR predictor
+        BoundPartials b[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) bound_init(b[c]);
+        // the differences that precede the chunk (wrapping 32-bit: the true values fit, see phase_r_residual)
+        const uint32_t e1 = (uint32_t)x[-1] - (uint32_t)x[-2], e1b = (uint32_t)x[-2] - (uint32_t)x[-3],
+                       e1c = (uint32_t)x[-3] - (uint32_t)x[-4];
+        const uint32_t e2 = e1 - e1b, e2b = e1b - e1c;
+        uint32_t p1 = e1, p2 = e2, p3 = e2 - e2b;
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) {
+            const uint32_t x0 = (uint32_t)x[i];
+            const uint32_t d1 = x0 - (uint32_t)x[i - 1], d2 = d1 - p1, d3 = d2 - p2, d4 = d3 - p3;
+            p1 = d1;
+            p2 = d2;
+            p3 = d3;
+            const int32_t fir = (int32_t)(x0 - (uint32_t)((3 * x[i - 1] - x[i - 2]) >> 2));  // |3 x1 - x2| <= 2^26
+            const bool w1 = first && i < 1, w2 = first && i < 2, w3 = first && i < 3, w4 = first && i < 4;
+            bound_add(b[0], live(i, (int32_t)x0));
+            bound_add(b[1], live(i, (int32_t)(w1 ? x0 : d1)));
+            bound_add(b[2], live(i, (int32_t)(w2 ? x0 : d2)));
+            bound_add(b[3], live(i, (int32_t)(w3 ? x0 : d3)));
+            bound_add(b[4], live(i, (int32_t)(w4 ? x0 : d4)));
+            bound_add(b[5], live(i, w2 ? (int32_t)x0 : fir));
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[c] = b[c];
+    }
+    for (int ci = 0; ci < 5; ++ci) {  // LPC orders 4, 6, 8, 10, 12 (open-loop Q15, ref lpc/lpc.cpp:38-61)
+        BoundPartials b;
+        bound_init(b);
+        const int ord = lpc_off ? 0 : (int)sh.lpc.used[ci];
+        auto lpc = [&](auto taps_tag) {
+            constexpr int TAPS = decltype(taps_tag)::value;
+            int32_t c[TAPS + 1];
+#pragma unroll
+            for (int t = 1; t <= TAPS; ++t) c[t] = (t <= ord) ? (int32_t)sh.lpc.coef[ci][t] : 0;
+#pragma unroll
+            for (int i = 0; i < G::CH; ++i) {
+                int64_t acc = 0;
+#pragma unroll
+                for (int t = 1; t <= TAPS; ++t) acc += (int64_t)c[t] * (int64_t)x[i - t];
+                // only the low 32 bits of the prediction matter (the residual fits int32 in the validated domain)
+                const int32_t r = (int32_t)((uint32_t)x[i] - (uint32_t)((uint64_t)acc >> 15));
+                bound_add(b, live(i, r));
+                }
+        };
+        if (ord == 0) {
+            // not available (uniform): nothing to add
+        } else if (ord <= 4) lpc(std::integral_constant<int, 4>{});
+        else if (ord <= 6) lpc(std::integral_constant<int, 6>{});
+        else if (ord <= 8) lpc(std::integral_constant<int, 8>{});
+        else if (ord <= 10) lpc(std::integral_constant<int, 10>{});
+        else lpc(std::integral_constant<int, 12>{});
+        out[6 + ci] = b;
+    }
 }
 
 // Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.

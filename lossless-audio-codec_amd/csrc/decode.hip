@@ -48,9 +48,11 @@ constexpr size_t kDecBytesPerCol = 256 * 4 + 32 * 4 + 32 * 2;
 // register (buf: `have` valid bits from r.pos on, left-aligned, zeros below) and fetches the stream as 64-bit words one
 // word AHEAD of the one it is consuming (nxt, byte-swapped only when it becomes current, so that nothing waits for the
 // load before it is needed).  Positions are 32-bit, relative to the block (a block's bitstream is far below 2^32 bits).
-// Bounds are not checked read by read: a read past the end of the block yields bits of the next block or of the 32
-// zero bytes behind the payload (always mapped), and the caller compares r.pos with r.nbits once per trip (overrun());
-// only the unbounded loop of a long unary run checks as it goes.
+// Bounds are not checked read by read: a read past the end of the block yields bits of the next block or of the
+// kDecodeTailPad zero bytes the host appends to the payload, and the caller compares r.pos with r.nbits once per trip
+// (overrun()); every loop whose length the stream controls (the coefficient list, a long unary run, the partition
+// table) checks BEFORE it reads.  Worst overshoot of one trip from r.pos <= r.nbits: 2 tag bits + 64 unary bits at hand
+// + 32 remainder bits = 13 bytes, plus the reader's two 8-byte words of look-ahead: 37 bytes < kDecodeTailPad.
 struct BitIn {
     const uint8_t* p;
     uint32_t nbits, pos, have, widx;  // widx: index of cur
@@ -218,6 +220,9 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
         return 2;
     }
     if (type == 2u) {
+        // the coefficient list is as long as the stream says (up to 32 x 16 bits): it must lie inside the block before
+        // a single bit of it is fetched (a block that ends right behind a type-2 header must not be read past its pad)
+        if (r.pos + 16u * (uint32_t)order > r.nbits) return 2;
         for (int i = 0; i < order; ++i) dm.coef((uint32_t)i, lane) = (int16_t)get_bits(r, 16);
         for (int i = order; i < 12; ++i) dm.coef((uint32_t)i, lane) = 0;  // the synthesis always walks twelve taps
         if (overrun(r)) return 2;

@@ -90,7 +90,10 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
 hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
                              unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream);
 
-// The decoder (decode.hip): one lane per block; payload must be padded with 32 readable bytes.  byte_off / frame_off:
+// The decoder (decode.hip): one lane per block; payload must be followed by kDecodeTailPad readable zero bytes (the bit
+// reader's bounded look-ahead past the last block, see BitIn).
+constexpr size_t kDecodeTailPad = 128;
+// The decoder's entry points:  byte_off / frame_off:
 // [num_blocks + 1] prefix sums of the block table; status[blk] = 0 or an error code, ms_flag[blk] = the block's LR/MS flag.
 hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int bit_depth, const uint8_t* payload,
                          const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,

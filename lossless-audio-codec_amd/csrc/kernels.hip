@@ -950,26 +950,46 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     STAMP(0);
 
     // ---- pass 1: the pruning bound of every candidate ------------------------------------------------------------
-    // Residual in registers -> bound partials -> block sums in sh.lbacc[cand]; nothing is stored and no barrier separates
-    // the candidates (ref block/encoder.cpp:362-407 walks them one by one).
-    for (int cand = 0; cand <= 10; ++cand) {
-        if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;  // uniform (shared memory, stable)
-        if (cand >= 6 && (prm.debug_skip & 16u)) continue;
-        if (cand >= 1 && (prm.debug_skip & 64u)) continue;
+    // One walk over the chunk for all eleven candidates (pass1_bounds, analyze_core.h): window loaded once, nothing
+    // stored, no barrier between candidates (ref block/encoder.cpp:362-407 walks them one by one).  Per candidate the
+    // thread holds the sum of its leading-bit counts and a 2-bit code per position (zero / four / other) that is counted
+    // once per chunk.
+    {
         // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
-        // addresses and masks derived from it out of this loop and, at the 128-VGPR budget, spills them to scratch.
+        // addresses and masks derived from it and, at the 128-VGPR budget, spills them to scratch.
         asm volatile("" : "+v"(th.a));
-        uint32_t ures[G::CH];
-        phase_r_residual(th, sh, cand, ures);
-        // block sums for the pruning bound (device form of the partials: see phase_r_residual)
-        const uint32_t g = wave_sum_u32(th.lb_g);
-        if ((tid & 63) == 0) {
-            const int32_t left = (int32_t)n - (int32_t)((tid >> 6) * 64 * G::CH);  // samples of the slot from this wave's first one on
-            const uint32_t valid = left <= 0 ? 0u : (left >= 64 * G::CH ? (uint32_t)(64 * G::CH) : (uint32_t)left);
-            const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
-            atomicAdd(&sh.lbacc[cand][0], g - th.lb_wz);
-            atomicAdd(&sh.lbacc[cand][1], (th.lb_wz - beyond) + (th.lb_wf << 16));
-            atomicAdd(&sh.lbacc[cand][2], th.lb_ends);
+        BoundPartials bp[11];
+        const bool lpc_off = (prm.debug_skip & 16u) != 0u;
+        if (n == (uint32_t)G::MAXN) pass1_bounds<G, true>(th, sh, lpc_off, bp);  // uniform
+        else pass1_bounds<G, false>(th, sh, lpc_off, bp);
+        // bit_width(u | 1) + 1 = 33 - clz(u | 1) = 34 - lead_m per position.  A zero counts 2 that way and is worth 1 (the
+        // wave's zero count takes the difference out); a position beyond the slot (r = 0) counts 2, is among those zeros
+        // and is worth nothing (the wave's `beyond` takes the rest out).
+        // Two candidates share a register for the wave sums (each sum stays below 2^16: 64 lanes x 34 x CH).
+        const uint32_t per_thread = 34u * (uint32_t)G::CH;
+        const int32_t left = (int32_t)n - (int32_t)((tid >> 6) * 64 * G::CH);  // samples of the slot from this wave's first one on
+        const uint32_t valid = left <= 0 ? 0u : (left >= 64 * G::CH ? (uint32_t)(64 * G::CH) : (uint32_t)left);
+        const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
+#pragma unroll
+        for (int c = 0; c < 12; c += 2) {
+            const uint32_t lo = per_thread - bp[c].msum, hi = c + 1 < 11 ? per_thread - bp[c + 1 < 11 ? c + 1 : c].msum : 0u;
+            const uint32_t g2 = wave_sum_u32(lo | (hi << 16));
+            const uint32_t cnt0 = wave_sum_u32(bound_counts<G::CH>(bp[c]));
+            const uint32_t cnt1 = c + 1 < 11 ? wave_sum_u32(bound_counts<G::CH>(bp[c + 1 < 11 ? c + 1 : c])) : 0u;
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cc = c + h;
+                    if (cc < 11) {
+                        const uint32_t g = h ? (g2 >> 16) : (g2 & 0xFFFFu);
+                        const uint32_t cnt = h ? cnt1 : cnt0;
+                        const uint32_t nz = cnt & 0x7FFu, n4 = (cnt >> 11) & 0x7FFu, ends = cnt >> 22;
+                        atomicAdd(&sh.lbacc[cc][0], g - nz - beyond);
+                        atomicAdd(&sh.lbacc[cc][1], (nz - beyond) + (n4 << 16));
+                        atomicAdd(&sh.lbacc[cc][2], ends);
+                    }
+                }
+            }
         }
     }
     STAMP(2);

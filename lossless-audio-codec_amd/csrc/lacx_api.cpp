@@ -665,8 +665,18 @@ struct HostSrc {
 };
 
 // Part 1: enqueue everything (no host synchronisation).
+int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                             hipStream_t user_stream, int layout, int layout_channels, const HostSrc* hs);
 int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                         hipStream_t user_stream, int layout = 0, int layout_channels = 0, const HostSrc* hs = nullptr) {
+    const int rc = encode_device_begin_impl(e, d_left, d_right, frames, user_stream, layout, layout_channels, hs);
+    // A failure half-way leaves kernels queued that write to the workspace, the slots and the pinned result buffer: they
+    // must have drained before the next call clears, frees or regrows any of those.
+    if (rc != LACX_OK && e->device_ready) (void)hipDeviceSynchronize();
+    return rc;
+}
+int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
+                             hipStream_t user_stream, int layout, int layout_channels, const HostSrc* hs) {
     if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
     const int channels = layout ? layout_channels : (d_right ? 2 : 1);
     const uint32_t nb = blocks_for(frames);
@@ -1554,9 +1564,10 @@ int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out) 
         if (frames > 6912000000ull) return decode_fail(LACX_E_INVALID, "[decode-error] total samples exceed maximum");
         if (version >= 3) {
             const uint32_t by = be32(lac + 18 + 8ull * b);
-            // (no token is longer than 34 + 32 bits, so a block's two channel bitstreams stay far below 16 MiB; the device
-            // reader's bit positions are 32-bit)
-            if (by == 0 || by > (1u << 24)) return decode_fail(LACX_E_INVALID, "[decode-error] invalid compressed block size");
+            // The device reader's bit positions are 32-bit and relative to the block: a block must stay below 2^29 bytes.
+            // (The reference takes any non-zero size that fits the file; a block this long -- a Rice token at k = 0 may
+            // carry a unary part of up to 2^30 bits -- is a documented deviation, see lacx.h.)
+            if (by == 0 || by >= (1u << 29)) return decode_fail(LACX_E_INVALID, "[decode-error] invalid compressed block size");
             pay += by;
             if (pay > size) return decode_fail(LACX_E_INVALID, "[decode-error] compressed block sizes exceed frame payload");
         }
@@ -1612,9 +1623,14 @@ int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, in
     uint8_t* d_ms = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<uint32_t> status(nb);
-    if (device >= 0) DEC_TRY(hipSetDevice(device), "hipSetDevice");
-    DEC_TRY(hipMalloc((void**)&d_pay, pay + 32), "hipMalloc(payload)");  // the bit reader fetches up to three words ahead
-    DEC_TRY(hipMemset(d_pay + pay, 0, 32), "memset");
+    int prev_device = -1;  // the caller's current device is put back on the way out
+    if (device >= 0) {
+        DEC_TRY(hipGetDevice(&prev_device), "hipGetDevice");
+        if (prev_device == device) prev_device = -1;
+        else DEC_TRY(hipSetDevice(device), "hipSetDevice");
+    }
+    DEC_TRY(hipMalloc((void**)&d_pay, pay + kDecodeTailPad), "hipMalloc(payload)");  // the bit reader's look-ahead (decode.hip)
+    DEC_TRY(hipMemset(d_pay + pay, 0, kDecodeTailPad), "memset");
     DEC_TRY(hipMemcpy(d_pay, lac + head, pay, hipMemcpyHostToDevice), "H2D payload");
     DEC_TRY(hipMalloc((void**)&d_offs, offs.size() * sizeof(unsigned long long)), "hipMalloc(offsets)");
     DEC_TRY(hipMemcpy(d_offs, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "H2D offsets");
@@ -1655,6 +1671,7 @@ done:
     if (d_right) (void)hipFree(d_right);
     if (d_status) (void)hipFree(d_status);
     if (d_ms) (void)hipFree(d_ms);
+    if (prev_device >= 0) (void)hipSetDevice(prev_device);
     return rc;
 }
 

@@ -107,11 +107,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # diagnostic: A/B runs of differently built libraries (scripts/kexp.py); never set in production
+        path = os.environ.get("LACX_LIB_OVERRIDE") or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `make -C {HERE}` (or __graft_entry__.build()); "
+                f"{path} is missing: build it with `make -C {HERE}` (or __graft_entry__.build()); "
                 "the LAC encode path has no Python/CPU fallback")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         L.lacx_last_error.restype = C.c_char_p
         L.lacx_last_error.argtypes = [C.c_void_p]
         L.lacx_free.argtypes = [C.c_void_p]

@@ -9,7 +9,7 @@ shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end $@"
+B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-other-workloads $@"
 run() {  # name, env prefix vars..., then rocprof args
   local name=$1; shift
   echo "== $name" >> $OUT/progress.log

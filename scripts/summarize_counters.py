@@ -18,6 +18,9 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_source_sha256  # noqa: E402  (the hash bench.py checks before it quotes these files)
+
 tag = sys.argv[1]
 default = not (len(sys.argv) > 3 and sys.argv[2] == "--workload-tag" and sys.argv[3] != "default")
 src = os.path.join(root, "gpurun_out", tag)
@@ -77,6 +80,7 @@ if default and derived:
     c = counters[full]
     json.dump({
         "kernel": "k_analyze<16,1024>",
+        "kernel_source_sha256": kernel_source_sha256(),
         "valu_wave_insts_per_step": derived["valu_wave_insts"],
         "salu_wave_insts_per_step": derived["salu_wave_insts"],
         "valu_busy_frac": derived["valu_busy_frac_at_effective_clock"],
@@ -95,6 +99,7 @@ if default and derived:
         blocks = 1758
         json.dump({
             "kernel": "k_analyze<16,1024>",
+            "kernel_source_sha256": kernel_source_sha256(),
             "command": "bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end (default workload: interleaved int16 device PCM, device emit), "
                        "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_valu.sh)",
             "launches_per_step": launches,

@@ -74,21 +74,39 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
     const int max_valid_order = (n > 1) ? (int)((n - 1 < 32u) ? n - 1 : 32u) : 0;
     levinson_candidates(r, max_valid_order, sh.lpc.coef, sh.lpc.used);
     sh.best_cand = -1;
-    for (int ci = 0; ci <= 10; ++ci) {
-        const int cand = candidate_at(ci);
-        if (cand >= 6 && sh.lpc.used[cand - 6] == 0) continue;
+    // pass 1: the pruning bounds of all candidates from one walk per thread (pass1_bounds), as in the kernel
+    uint64_t cand_key[11];
+    {
+        uint32_t g[11] = {0}, nz[11] = {0}, n4[11] = {0}, ends[11] = {0};
+        for (int t = 0; t < G::T; ++t) {
+            BoundPartials bp[11];
+            if (n == (uint32_t)G::MAXN) pass1_bounds<G, true>(th[t], sh, false, bp); else pass1_bounds<G, false>(th[t], sh, false, bp);
+            const uint32_t beyond = (uint32_t)(G::CH - th[t].cnt);
+            for (int c = 0; c < 11; ++c) {
+                g[c] += 34u * (uint32_t)G::CH - bp[c].msum - bp[c].nz - beyond;
+                nz[c] += bp[c].nz - beyond;
+                n4[c] += bp[c].n4;
+                ends[c] += bp[c].ends;
+            }
+        }
+        for (int c = 0; c < 11; ++c) {
+            const bool avail = !(c >= 6 && sh.lpc.used[c - 6] == 0);
+            cand_key[c] = avail ? ((candidate_lower_bound(g[c], nz[c] + (n4[c] << 16), ends[c], n, zero_run) << 4) | (uint64_t)c) : ~0ull;
+        }
+    }
+    // pass 2: exact costs in ascending (bound, index) order; the first candidate that cannot win ends the search
+    uint32_t tried = 0;
+    for (;;) {
+        uint64_t best_key = ~0ull;
+        for (int c = 0; c < 11; ++c)
+            if (!((tried >> c) & 1u) && cand_key[c] < best_key) best_key = cand_key[c];
+        if (best_key == ~0ull) break;
+        const int cand = (int)(best_key & 15u);
+        if (!(force_wide & 4) && candidate_pruned(best_key >> 4, cand, sh.best_bits, sh.best_cand)) break;
+        tried |= 1u << cand;
         for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, cand);
         scans_after_r(sh);
         plane_totals(sh, th);
-        {
-            uint32_t g = 0, a = 0, e = 0;
-            for (int t = 0; t < G::T; ++t) {
-                g += th[t].lb_g;
-                a += th[t].lb_aux;
-                e += th[t].lb_ends;
-            }
-            if (!(force_wide & 4) && candidate_pruned(candidate_lower_bound(g, a, e, n, zero_run), cand, sh.best_bits, sh.best_cand)) continue;
-        }
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
         const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
         for (int t = 0; t < G::T; ++t) {

@@ -149,6 +149,18 @@ def test_damaged_streams_are_refused(gpu):
     bad[off1 + 1] = 7
     with pytest.raises(RuntimeError, match=r"decode-error\] block=1"):
         gpu.lacx.decode(bytes(bad))
+    # the stream ends right behind a type-2 (LPC) channel header that announces 32 coefficients: the coefficient list
+    # must be refused before it is read (it would reach 64 bytes past the payload)
+    ml, _ = gpu.synth.synth_pcm(16384 + 100, 1, 16, 48000, seed=6, kind="music")
+    mono = gpu.lacx.Encoder(12, 0, 48000, 16).encode(ml, None)
+    mi = gpu.lacx.stream_parse(mono)
+    assert mi.blocks == 2
+    mhead = 14 + 8 * mi.blocks
+    m0 = int.from_bytes(mono[18:22], "big")
+    cut = bytearray(mono[:mhead + m0] + b"\x02\x20")
+    cut[26:30] = (2).to_bytes(4, "big")
+    with pytest.raises(RuntimeError, match=r"decode-error\] block=1"):
+        gpu.lacx.decode(bytes(cut))
     # random damage inside the payload: refused or decoded to something else, never a hang or a crash
     rng = np.random.default_rng(3)
     for _ in range(20):
