@@ -123,10 +123,10 @@ LACX_HD int clz32(uint32_t v) {
 //   block/encoder.cpp:72-77) == the smallest k with mean <= 2^k, i.e. with (X - c) < (c << k), X = S + (c>>1).
 LACX_HD uint32_t kmean(uint64_t S, uint32_t c) {
     const uint64_t X = S + (c >> 1);
-    if (X < 2ull * c) return 0;
-    const uint64_t Y = X - c;  // >= c
+    const uint64_t Y = X - c;  // >= c when the mean exceeds 1 (garbage otherwise: selected away below, no branch)
     const int g = clz64((uint64_t)c) - clz64(Y);  // bit_width(Y) - bit_width(c) >= 0
-    return (uint32_t)g + ((Y >> g) >= c ? 1u : 0u);
+    const uint32_t k = (uint32_t)g + ((Y >> (g & 63)) >= c ? 1u : 0u);
+    return (X < 2ull * c) ? 0u : k;
 }
 // same, for S + (c>>1) < 2^32
 LACX_HD uint32_t kmean32(uint32_t S, uint32_t c) {
@@ -150,33 +150,43 @@ LACX_HD uint64_t rice_cost(uint32_t u, uint32_t k) {  // ref block/encoder.cpp:6
 //   P = sum of u over [0,c), W = sum over [0, c-256), flag counts d = large | zero<<16 over the last 96.
 // Division-free: with mean = floor(X/c), X = P + (c>>1):
 //   3L > 4 mean  <=>  X < ceil(3L/4) * c          4L+3 < 3 mean  <=>  X >= (floor((4L+3)/3) + 1) * c
-template <bool NARROW>
+// 0 / 1 in a vector register.  On the device the value is pinned there: flags that are combined as integers stay on the
+// vector unit.  Left to itself the compiler keeps comparison results as lane masks in scalar registers, combines them
+// with scalar instructions and turns selects between costly operands into divergent branches -- each a round trip
+// vector compare -> scalar unit -> execution mask, which is what the adaptive-cost loops spent a third of their time on.
+LACX_HD uint32_t flag01(bool b) {
+    uint32_t v = b ? 1u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// STEADY: the caller guarantees c > 256 (hence also c >= 96): every chunk but the first 256 / CH of a slot.
+template <bool NARROW, bool STEADY = false>
 LACX_HD uint32_t biased_k(uint32_t km, uint64_t P, uint64_t W, uint32_t d, uint32_t c) {
     // local mean of the last 256 (ref rice.hpp:85-87); u < 2^30 keeps L, U, D inside 32 bits
     const uint32_t L = NARROW ? ((((uint32_t)P - (uint32_t)W) + 128u) >> 8) : (uint32_t)(((P - W) + 128u) >> 8);
     const uint32_t U = (3u * L + 3u) >> 2;
     const uint32_t D = L + (L + 3u) / 3u + 1u;
-    bool up, dn;
-    if (NARROW) {
-        const uint32_t X = (uint32_t)P + (c >> 1);
-        const bool act = (c > 256u) & (X >= c);
-        up = act & ((uint64_t)X < (uint64_t)U * c);
-        dn = act & ((uint64_t)X >= (uint64_t)D * c);
-    } else {
-        const uint64_t X = P + (c >> 1);
-        const bool act = (c > 256u) & (X >= c);
-        up = act & (X < (uint64_t)U * c);
-        dn = act & (X >= (uint64_t)D * c);
-    }
-    int bias = up ? 1 : (dn ? -1 : 0);
+    const uint64_t X = NARROW ? (uint64_t)((uint32_t)P + (c >> 1)) : P + (c >> 1);
+    const uint64_t Uc = (uint64_t)U * c, Dc = (uint64_t)D * c;  // both products always: no branch around the second
+    // drift (ref rice.hpp:88-95): U c <= D c, so "up" and "down" exclude each other
+    uint32_t act = flag01(X >= (uint64_t)c);
+    if (!STEADY) act &= flag01(c > 256u);
+    const int32_t drift = (int32_t)(act & flag01(X < Uc)) - (int32_t)(act & flag01(X >= Dc));
     // micro window (ref rice.hpp:97-105): large*4 >= 96*3 <=> large >= 72 ; zero*5 >= 96*4 <=> zero >= 77
     const uint32_t large = d & 0xFFFFu, zero = d >> 16;
-    const bool m = c >= 96u;
-    const bool big = m & (large >= 72u);
-    const bool sml = m & (zero >= 77u) & !big;
-    const int bp = bias + 1 < 1 ? bias + 1 : 1;
-    const int bm = bias - 1 > -1 ? bias - 1 : -1;
-    bias = big ? bp : (sml ? bm : bias);
+    uint32_t big = flag01(large >= 72u), sml = flag01(zero >= 77u);
+    if (!STEADY) {
+        const uint32_t m = flag01(c >= 96u);
+        big &= m;
+        sml &= m;
+    }
+    sml &= big ^ 1u;
+    // big: min(drift + 1, 1); small: max(drift - 1, -1); neither: drift -- one clamp of drift + big - small
+    int32_t bias = drift + (int32_t)big - (int32_t)sml;
+    bias = bias < -1 ? -1 : (bias > 1 ? 1 : bias);
     int bk = (int)km + bias;
     bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
     return (uint32_t)bk;
@@ -198,6 +208,10 @@ struct PartMem {
     uint32_t segrun[G::NSEG];
     uint8_t choice[G::NSEG];
     unsigned long long pbits[G::MAXP + 1];
+    // partition_quick: (chunk, order) pairs whose Rice parameter is not provably constant over the chunk, left to
+    // partition_slow_entry; entry = chunk | (order - 1) << 12.  One region of 64 * MAXP entries per wave.
+    uint32_t qcount;  // (host simulator only)
+    uint16_t queue[G::T * G::MAXP];
 };
 
 // Output side of the device emit (emit_core.h): the bit tile and the Rice parameter in force per sample.  Aliases the
@@ -799,60 +813,74 @@ LACX_HD uint32_t window_flags(const uint32_t* tabF, int t) {
 
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
 // (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
-template <class G, bool NARROW, bool ZR = true>
+// FULL: every chunk of the slot is complete (n == MAXN, block-uniform): a fixed trip count, no per-lane loop exit.
+// STEADY: the chunk starts at sample 256 or later (wave-uniform: every wave but the first of a 1024-thread slot): the
+// window taps exist and the count thresholds of the bias are met throughout.
+template <class G, bool NARROW, bool ZR = true, bool FULL = false, bool STEADY = false>
 LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     const int t = th.tid;
     const uint32_t n = th.n;
     uint64_t P = sh.tabP[t];                                   // P_{a-1}
-    uint64_t W = (t >= G::W256) ? sh.tabP[t - G::W256] : 0;    // P_{a-1-256}
+    uint64_t W = (STEADY || t >= G::W256) ? sh.tabP[t - (STEADY || t >= G::W256 ? G::W256 : 0)] : 0;    // P_{a-1-256}
     // packed flag counts over the 96 samples before the chunk = its W96 predecessors' chunk counts (the window
     // starts on a chunk boundary); kept up to date sample by sample below
     uint32_t D = window_flags<G>(sh.tabF, t);
-    const uint32_t m256 = (t >= G::W256) ? 0x3FFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
-    const uint32_t m96 = (t >= G::W96) ? 0xFFFFFFFFu : 0u;
-    const int t256 = (t >= G::W256) ? t - G::W256 : t;
-    const int t96 = (t >= G::W96) ? t - G::W96 : t;
+    const uint32_t m256 = (STEADY || t >= G::W256) ? 0x3FFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
+    const uint32_t m96 = (STEADY || t >= G::W96) ? 0xFFFFFFFFu : 0u;
+    const int t256 = (STEADY || t >= G::W256) ? t - G::W256 : t;
+    const int t96 = (STEADY || t >= G::W96) ? t - G::W96 : t;
     uint32_t c = (uint32_t)th.a;
     // k in force for the first sample of the chunk: the value returned after sample a-1
     uint32_t kin = k0;
-    if (th.a > 0 && th.cnt > 0) kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
+    if (STEADY || (th.a > 0 && th.cnt > 0)) kin = biased_k<NARROW, STEADY>(kmean_t<NARROW>(P, c), P, W, D, c);
     int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
     // chunk sums: 32 bits suffice on the narrow path (each cost <= u + 34 and the block's sum of u is < 2^31)
     using Acc = typename std::conditional<NARROW, uint32_t, unsigned long long>::type;
     Acc rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
     uint32_t w0 = sh.u[t];  // own sample incl. flags
-    uint32_t n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n), n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n),
-             n3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
+    uint32_t n1 = 1, n2 = 1, n3 = 1;
+    if (ZR) {
+        n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n);
+        n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n);
+        n3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
+    }
+    const int trips = FULL ? G::CH : th.cnt;
+    // the window taps of the current trip are fetched one trip ahead (their latency hides behind the trip's arithmetic)
+    uint32_t tap256 = sh.u[t256], tap96 = sh.u[t96];
 #pragma nounroll  // one sample per trip: the 16-fold body does not fit the register budget
-    for (int i = 0; i < G::CH; ++i) {
-        if (i >= th.cnt) break;
+    for (int i = 0; i < trips; ++i) {
+        const uint32_t cur256 = tap256, cur96 = tap96;
+        const int inext = (i + 1) & (G::CH - 1);
+        const uint32_t wnext = sh.u[inext * G::T + t];
+        tap256 = sh.u[inext * G::T + t256];
+        tap96 = sh.u[inext * G::T + t96];
         const uint32_t u = w0 & 0x3FFFFFFFu;
         const uint32_t rc = (u >> kin) + 1u + kin;  // kin <= 31 (biased_k clamps) and u < 2^30: no k >= 31 special case
         rice += rc;
-        bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
+        bin += 2u + ((u <= 4u) ? (u < 1u ? u : 1u) : rc);  // 2 for a zero, 3 for 1..4, else 2 + the Rice code
         if (ZR) {
-            const bool z = (u == 0);
-            f = z ? f + 1 : 0;
-            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-            const bool in4 = z & (f + ahead >= 4);
+            const uint32_t z = flag01(u == 0u);
+            f = (f + 1) & (int32_t)(0u - z);
+            const uint32_t ahead = (n1 != 0) ? 0u : ((n2 != 0) ? 1u : ((n3 != 0) ? 2u : 3u));
+            const uint32_t in4 = z & flag01((uint32_t)f + ahead >= 4u);
             const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
             const uint32_t plain = 2u + ((u > esc) ? 32u : rc);              // not inside a run of >= 4
             const uint32_t token = 5u + (((uint32_t)(f - 4)) >> 2);          // last sample of such a run
-            const bool runend = in4 & (n1 != 0);
-            zr += in4 ? (runend ? token : 0u) : plain;
-            hasrun |= runend ? 1u : 0u;
+            const uint32_t runend = in4 & flag01(n1 != 0);
+            zr += (plain & (in4 - 1u)) | (token & (0u - runend));            // in4 - 1: all ones outside a run
+            hasrun |= runend;
         }
         // state after this sample -> k for the next one
         P += u;
         ++c;
-        W += sh.u[i * G::T + t256] & m256;
-        const uint32_t w96 = sh.u[i * G::T + t96] & m96;
+        W += cur256 & m256;
+        const uint32_t w96 = cur96 & m96;
         D += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);       // sample j enters the window ...
         D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);     // ... sample j-96 leaves it
-        kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
+        kin = biased_k<NARROW, STEADY>(kmean_t<NARROW>(P, c), P, W, D, c);
         // slide the lookahead window
-        w0 = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
+        w0 = wnext;
         if (ZR) {
             n1 = n2;
             n2 = n3;
@@ -863,6 +891,26 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     th.cbin = bin;
     th.czr = zr;
     th.chasrun = hasrun;
+}
+
+// Picks the instance of phase_b: narrow / zr / full are block-uniform; the chunk-position instance (STEADY) is taken by
+// every wave but the first of a multi-wave slot (a >= 64 * CH >= 256, wave-uniform).
+template <class G>
+LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, bool narrow, bool zr, bool full) {
+    const bool steady = G::T > 64 && th.tid >= 64 && 64 * G::CH >= 256;
+    auto go = [&](auto narrow_t, auto zr_t) {
+        constexpr bool N = decltype(narrow_t)::value, Z = decltype(zr_t)::value;
+        if (full) {
+            if (steady) phase_b<G, N, Z, true, true>(th, sh, k0); else phase_b<G, N, Z, true, false>(th, sh, k0);
+        } else {
+            if (steady) phase_b<G, N, Z, false, true>(th, sh, k0); else phase_b<G, N, Z, false, false>(th, sh, k0);
+        }
+    };
+    if (narrow) {
+        if (zr) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{});
+    } else {
+        if (zr) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{});
+    }
 }
 
 // Exact lower bound on min(rice, static, zero-run, bin) of a candidate, from four block sums:
@@ -1020,7 +1068,7 @@ LACX_HD void seg_static_eval(Smem<G>& sh, uint32_t n, int p, uint32_t part) {
 // Stateless adaptive pass of one partition order over the thread's chunk
 // (ref block/encoder.cpp:201-263 with adapt_k_stateless :72-77).  Partial sums leave through `flush`.
 // sh.u holds the plain residual (no flag bits) in this phase.
-template <class G, bool NARROW, class Flush>
+template <class G, bool NARROW, bool ZR = true, class Flush>
 LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush&& flush) {
     if (th.cnt <= 0) return;
     const uint32_t n = th.n;
@@ -1062,19 +1110,21 @@ LACX_HD void partition_pass(const Thread<G>& th, const Smem<G>& sh, int p, Flush
         const uint32_t rc = ((kin >= 31u) ? 0u : (u >> kin)) + 1u + kin;
         rice += rc;
         bin += (u == 0) ? 2u : ((u <= 4u) ? 3u : 2u + rc);
-        const bool z = (u == 0);
-        f = z ? f + 1 : 0;
-        const uint32_t n1 = (j + 1u < e) ? x1 : 1u;
-        const uint32_t n2 = (j + 2u < e) ? x2 : 1u;
-        const uint32_t n3 = (j + 3u < e) ? x3 : 1u;
-        const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
-        const bool in4 = z && (f + ahead >= 4);
-        if (!in4) {
-            const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
-            zr += 2u + ((u > esc) ? 32u : rc);
-        } else if (n1 != 0) {
-            zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
-            hasrun = 1;
+        if (ZR) {
+            const bool z = (u == 0);
+            f = z ? f + 1 : 0;
+            const uint32_t n1 = (j + 1u < e) ? x1 : 1u;
+            const uint32_t n2 = (j + 2u < e) ? x2 : 1u;
+            const uint32_t n3 = (j + 3u < e) ? x3 : 1u;
+            const int ahead = (n1 != 0) ? 0 : ((n2 != 0) ? 1 : ((n3 != 0) ? 2 : 3));
+            const bool in4 = z && (f + ahead >= 4);
+            if (!in4) {
+                const uint32_t esc = 1u << ((kin + 3u) < 24u ? (kin + 3u) : 24u);
+                zr += 2u + ((u > esc) ? 32u : rc);
+            } else if (n1 != 0) {
+                zr += 2u + (((uint32_t)(f - 4)) >> 2) + 3u;
+                hasrun = 1;
+            }
         }
         P += u;
         u = x1;
@@ -1098,7 +1148,9 @@ LACX_HD bool partitions_chunk_aligned(uint32_t n, int max_p) {
 // Same numbers as partition_pass<G, true> run for p = 1..max_p.
 template <class G, bool ZR = true, class Flush>
 LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, Flush&& flush) {
-    if (th.cnt <= 0) return;
+    // Every lane of the wave reaches the flush (its sums go through wave-wide reductions on the device): a chunk beyond
+    // the slot contributes zeros.
+    const bool live = th.cnt > 0;
     const uint32_t n = th.n;
     const int t = th.tid;
     const uint32_t a = (uint32_t)th.a;
@@ -1113,7 +1165,7 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         s[q] = rem[q] = Pseg[q] = ak[q] = sidx[q] = 0;
         if (p <= max_p) {
             const uint32_t base = n >> p;
-            const uint32_t part = a / base;
+            const uint32_t part = !live ? 0u : ((n & (n - 1u)) == 0u ? a >> (31 - clz32(n) - p) : a / base);
             s[q] = part * base;
             rem[q] = s[q] + base - a;  // samples from a to the end of the partition
             Pseg[q] = (uint32_t)sh.tabP[s[q] / (uint32_t)G::CH];
@@ -1176,8 +1228,10 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
         x2 = x3;
         x3 = peek_u<G>(sh, j + 4u, n);
     };
-    sample(0, std::true_type{});
-    for (int i = 1; i < th.cnt; ++i) sample(i, std::false_type{});
+    if (live) {
+        sample(0, std::true_type{});
+        for (int i = 1; i < th.cnt; ++i) sample(i, std::false_type{});
+    }
 #pragma unroll
     for (int q = 1; q < G::MAXP; ++q) {
         if ((dup >> q) & 1u) {  // ascending: a run of repeated orders cascades
@@ -1187,8 +1241,124 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     }
 #pragma unroll
     for (int q = 0; q < G::MAXP; ++q) {
-        if (q < max_p) flush(sidx[q], rice[q], bin[q], zr[q], (hasrun >> q) & 1u);
+        if (q < max_p) flush(q, sidx[q], rice[q], bin[q], zr[q], (hasrun >> q) & 1u);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Partition search without walking the samples (no zero-run costs; 32-bit sums; partitions on chunk boundaries).
+// Inside a partition the Rice parameter of sample j is kmean(S_j, c_j) of the prefix sum S_j and the count c_j of the
+// partition's samples before j (ref block/encoder.cpp:72-77, 201-263).  kmean is monotone: it grows with S and falls
+// with c (the smallest k with S < c 2^k + ceil(c / 2)).  Over the samples a+1 .. a+CH-1 of a chunk S only grows and c
+// only grows, so every parameter in force there lies between kmean(S_first, c_last) and kmean(S_last, c_first).  Where
+// the two agree -- K -- the chunk's costs need no walk: sum (u >> K) comes from the thread's bit-sliced plane counts
+// (sum over the slices l of (cs[l] >> K) << l), and the bin code's exceptions (u <= 4) from a census of the small
+// values.  A chunk that opens its partition has its first sample costed by itself (it takes the partition's initial
+// k).  Chunks where the bounds disagree (about a quarter: the first few of every partition, where the prefix mean
+// still moves) are queued per wave and walked by partition_slow_entry, densely packed over the wave's lanes.
+// Same numbers as partition_fused<G, false>.
+// ---------------------------------------------------------------------------------------------
+// Census of the chunk's small values: 5-bit counts of u == 0, 1, 2, 3, 4 in fields 0..4, of u >= 5 in field 5.
+LACX_HD uint32_t census_code(uint32_t u) { return 1u << (5u * (u < 5u ? u : 5u)); }
+
+template <class G>
+LACX_HD uint32_t small_census(const Thread<G>& th, const Smem<G>& sh, uint32_t* u_first) {
+    uint32_t cen = 0;
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t u = sh.u[i * G::T + th.tid];
+        if (i == 0) *u_first = u;
+        cen += census_code(u);
+    }
+    return cen;
+}
+
+// sum over the census of (v >> K) for the small values v = 1..4
+LACX_HD uint32_t census_shift_sum(uint32_t cen, uint32_t K) {
+    const uint32_t n1 = (cen >> 5) & 31u, n2 = (cen >> 10) & 31u, n3 = (cen >> 15) & 31u, n4 = (cen >> 20) & 31u;
+    const uint32_t s0 = n1 + 2u * n2 + 3u * n3 + 4u * n4, s1 = n2 + n3 + 2u * n4, s2 = n4;
+    return K == 0u ? s0 : (K == 1u ? s1 : (K == 2u ? s2 : 0u));
+}
+
+template <class G, class Flush, class Enqueue>
+LACX_HD void partition_quick(const Thread<G>& th, const Smem<G>& sh, int max_p, Flush&& flush, Enqueue&& enqueue) {
+    // (chunks are complete or empty here; an empty chunk still takes part in the wave-wide steps of `enqueue`)
+    const bool live = th.cnt > 0;
+    const uint32_t n = th.n;
+    const int t = th.tid;
+    const uint32_t a = (uint32_t)th.a;
+    const uint32_t Pa = (uint32_t)sh.tabP[t];                 // P_{a-1}
+    const uint32_t csum = (uint32_t)sh.tabP[t + 1] - Pa;      // sum of the chunk
+    uint32_t u_first;
+    const uint32_t cen = small_census(th, sh, &u_first);
+    const uint32_t u_last = sh.u[(G::CH - 1) * G::T + t];
+    const uint32_t code_first = census_code(u_first);
+    // a / (n >> p) without a division when n is a power of two (every full block, every probe; block-uniform)
+    const bool n_pow2 = (n & (n - 1u)) == 0u;
+    const int log2n = 31 - clz32(n);
+    for (int q = 0; q < max_p; ++q) {
+        const int p = q + 1;
+        const uint32_t base = n >> p;
+        const uint32_t part = !live ? 0u : (n_pow2 ? a >> (log2n - p) : a / base);
+        const uint32_t s = part * base;
+        const uint32_t sidx = (2u << (p - 1)) - 2u + part;
+        const uint32_t Sa = Pa - (uint32_t)sh.tabP[s / (uint32_t)G::CH];  // sum of the partition's samples before a
+        const uint32_t ca = a - s;                                         // ... and their number
+        // A chunk that opens its partition (head) has its first sample costed by itself, with the partition's initial
+        // k; the constant-parameter test then covers samples a+1 .. a+CH-1, otherwise the whole chunk.
+        const bool head = ca == 0u;
+        const uint32_t klo = kmean32(head ? u_first : Sa, ca + (uint32_t)G::CH - 1u);
+        const uint32_t khi = kmean32(Sa + csum - u_last, head ? 1u : ca);
+        const bool ambiguous = live && klo != khi;
+        enqueue((uint32_t)t | ((uint32_t)q << 12), ambiguous);
+        const bool quick = live && !ambiguous;  // (the others pass zeros: every lane of the wave reaches the flush)
+        const uint32_t K = klo;
+        uint32_t shifted = 0;  // sum of u >> K over the chunk
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) shifted += (th.cs[l] >> K) << l;
+        const uint32_t k_a = (uint32_t)sh.xp.part.seginfo[sidx].ak;
+        const uint32_t rc_a = (u_first >> k_a) + 1u + k_a;               // head only
+        const uint32_t ncon = (uint32_t)G::CH - (head ? 1u : 0u);         // samples costed at K
+        const uint32_t cen_con = cen - (head ? code_first : 0u);
+        if (head) shifted -= u_first >> K;
+        const uint32_t rice = shifted + ncon * (1u + K) + (head ? rc_a : 0u);
+        // bin: 2 for a zero, 3 for 1..4, else 2 + the Rice code
+        const uint32_t n14 = ((cen_con >> 5) & 31u) + ((cen_con >> 10) & 31u) + ((cen_con >> 15) & 31u) + ((cen_con >> 20) & 31u);
+        const uint32_t nbig = (cen_con >> 25) & 31u;
+        const uint32_t bin_a = 2u + (u_first <= 4u ? (u_first < 1u ? u_first : 1u) : rc_a);
+        const uint32_t bin = 2u * ncon + n14 + (shifted - census_shift_sum(cen_con, K)) + nbig * (1u + K) + (head ? bin_a : 0u);
+        flush(q, sidx, quick ? rice : 0u, quick ? bin : 0u, 0u, 0u);
+    }
+}
+
+// One queued (chunk, order) pair of partition_quick: the plain walk over the chunk's samples (32-bit sums, no zero-run
+// costs, the whole chunk inside one partition).
+template <class G, class Flush>
+LACX_HD void partition_slow_entry(const Smem<G>& sh, uint32_t n, uint32_t entry, Flush&& flush) {
+    const uint32_t t = entry & 0xFFFu;
+    const int p = (int)(entry >> 12) + 1;
+    const uint32_t a = t * (uint32_t)G::CH;
+    const uint32_t base = n >> p;
+    const uint32_t part = (n & (n - 1u)) == 0u ? a >> (31 - clz32(n) - p) : a / base;  // (block-uniform choice)
+    const uint32_t s = part * base;
+    const uint32_t sidx = (2u << (p - 1)) - 2u + part;
+    uint32_t S = (uint32_t)sh.tabP[t] - (uint32_t)sh.tabP[s / (uint32_t)G::CH];  // sum of the partition's samples before j
+    uint32_t c = a - s;                                                           // ... and their number
+    uint32_t k = c == 0u ? (uint32_t)sh.xp.part.seginfo[sidx].ak : kmean32(S, c ? c : 1u);
+    uint32_t rice = 0, bin = 0;
+    uint32_t u = sh.u[t];
+#pragma unroll
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t unext = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
+        const uint32_t rc = (u >> k) + 1u + k;
+        rice += rc;
+        bin += 2u + (u <= 4u ? (u < 1u ? u : 1u) : rc);
+        S += u;
+        ++c;
+        k = kmean32(S, c);
+        u = unext;
+    }
+    flush(sidx, rice, bin, 0u, 0u);
 }
 
 // Mode choice of one partition (ref block/encoder.cpp:495-525); returns bits, writes (mode<<5)|k.

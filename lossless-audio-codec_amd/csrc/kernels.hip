@@ -133,6 +133,32 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return wave_last_
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_scan_add_u32(v)); }
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) { return wave_last_u32(wave_scan_or_u32(v)); }
 
+// Sum of v over the segment of (1 << LOG) consecutive lanes that contains the lane; valid in the segment's LAST lane
+// (segments are aligned: lanes [k << LOG, (k + 1) << LOG)).  The first LOG steps of the wave scan.
+// LDS atomics of many lanes on ONE address are serialised lane by lane: 1024 threads adding their partial sums to the
+// handful of accumulators of a low partition order cost more than the arithmetic that produced the sums -- hence one
+// atomic per segment instead of one per lane wherever the lanes that share an accumulator are neighbours.
+template <int LOG>
+__device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v) {
+    if (LOG >= 1) v += dpp_mov<kDppRowShr1, 0xF>(0u, v);
+    if (LOG >= 2) v += dpp_mov<kDppRowShr2, 0xF>(0u, v);
+    if (LOG >= 3) v += dpp_mov<kDppRowShr4, 0xF>(0u, v);
+    if (LOG >= 4) v += dpp_mov<kDppRowShr8, 0xF>(0u, v);
+    if (LOG >= 5) v += dpp_mov<kDppRowBcast15, 0xA>(0u, v);
+    if (LOG >= 6) v += dpp_mov<kDppRowBcast31, 0xC>(0u, v);
+    return v;
+}
+__device__ __forceinline__ uint32_t seg_sum_u32(uint32_t v, int log2_lanes) {  // log2_lanes wave-uniform, 1..6
+    switch (log2_lanes) {
+        case 1: return seg_sum_u32<1>(v);
+        case 2: return seg_sum_u32<2>(v);
+        case 3: return seg_sum_u32<3>(v);
+        case 4: return seg_sum_u32<4>(v);
+        case 5: return seg_sum_u32<5>(v);
+        default: return seg_sum_u32<6>(v);
+    }
+}
+
 // Block exclusive scans of the per-thread values the phases left in tabP/tabNZ (sum / max).
 // part 1 before the barrier, part 2 after it.
 template <class G>
@@ -1078,11 +1104,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         } else {
             // the zero-run cost only matters when the residual has a run of >= 4 zeros somewhere
             const bool zr = prm.zero_run && sh.has4[parity] != 0u;
-            if (narrow) {
-                if (zr) phase_b<G, true, true>(th, sh, k0); else phase_b<G, true, false>(th, sh, k0);
-            } else {
-                if (zr) phase_b<G, false, true>(th, sh, k0); else phase_b<G, false, false>(th, sh, k0);
-            }
+            phase_b_dispatch<G>(th, sh, k0, narrow, zr, n == (uint32_t)G::MAXN);
         }
         STAMP(12);
         {
@@ -1114,7 +1136,6 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     const int nseg = max_p > 0 ? ((2 << max_p) - 2) : 0;
     PartMem<G>& pm = sh.xp.part;
     auto clear_partition_scratch = [&]() {  // aliases the staged samples: only once every thread is done with them
-        for (int i = tid; i < 15 * (G::NG + 1); i += G::T) (&pm.grp[0][0])[i] = 0;
         for (int i = tid; i < nseg; i += G::T) {
             pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
             pm.segrun[i] = 0;
@@ -1142,10 +1163,19 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     STAMP(16);
     if (max_p > 0) {
         {
+            // the TPG neighbouring lanes of a 64-sample group own its table entry: sum them on the DPP network, one plain
+            // store by the group's last lane (no atomics; the entries need no clearing)
+            constexpr int kLog = G::TPG == 4 ? 2 : 4;
+            static_assert(G::TPG == 4 || G::TPG == 16, "lanes per 64-sample group");
             uint32_t words[15];
             packed_planes(th, words);
+            const bool last = (tid & (G::TPG - 1)) == G::TPG - 1;
 #pragma unroll
-            for (int w = 0; w < 15; ++w) atomicAdd(&pm.grp[w][tid / G::TPG], words[w]);
+            for (int w = 0; w < 15; ++w) {
+                const uint32_t v = seg_sum_u32<kLog>(words[w]);
+                if (last) pm.grp[w][tid / G::TPG] = v;
+            }
+            if (tid < 15) pm.grp[tid][G::NG] = 0;  // the slot past the last group (the scan's total)
         }
         __syncthreads();
         {
@@ -1175,18 +1205,65 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             // block no partition can have one, so the zero-run costs are not needed.  Narrow sums: every segment total
             // stays below 2^32 (sum of u < 2^31, at most 35 bits of overhead per sample), so 32-bit LDS atomics on the
             // low words of the (zeroed) 64-bit accumulators suffice.
-            auto flush32 = [&pm](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr) {
-                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
-                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
-                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+            // One atomic per accumulator and segment of neighbouring lanes (see seg_sum_u32): the lanes of a partition of
+            // order p are (n >> p) / CH neighbours -- a power of two for every full block and every probe; other sizes
+            // fall back to one atomic per lane.  Called by every lane of the wave (idle lanes pass zeros).
+            const bool ablate_flush = (prm.debug_skip & 65536u) != 0u;
+            const uint32_t chunks = n / (uint32_t)G::CH;  // chunks of the slot
+            const bool pow2 = (chunks & (chunks - 1u)) == 0u && !(prm.debug_skip & 131072u);
+            auto seg_flush = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr, bool with_zr) {
+                if (ablate_flush) return;
+                const uint32_t lanes = chunks >> (q + 1);  // lanes per partition of this order (wave-uniform)
+                if (pow2 && lanes >= 2u) {
+                    const int lg = lanes >= 64u ? 6 : 31 - __clz((int)lanes);
+                    const bool last = ((uint32_t)tid & ((1u << lg) - 1u)) == (1u << lg) - 1u;
+                    rc = seg_sum_u32(rc, lg);
+                    bn = seg_sum_u32(bn, lg);
+                    if (with_zr) zr = seg_sum_u32(zr, lg);
+                    if (last) {
+                        atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                        atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                        if (with_zr) atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                    }
+                } else {
+                    atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                    atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                    if (with_zr) atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                }
                 if (hr) atomicOr(&pm.segrun[idx], 1u);
             };
-            auto flush32_nozr = [&pm](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+            auto flush32 = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr) {
+                seg_flush(q, idx, rc, bn, zr, hr, true);
+            };
+            auto flush32_nozr = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+                seg_flush(q, idx, rc, bn, 0u, 0u, false);
+            };
+            // (one queued chunk of partition_quick: any partition, any order per lane)
+            auto flush_entry = [&pm, ablate_flush](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+                if (ablate_flush) return;
                 atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
                 atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
             };
-            if (prm.zero_run && sh.best_hasrun) partition_fused<G, true>(th, sh, max_p, flush32);
-            else partition_fused<G, false>(th, sh, max_p, flush32_nozr);
+            if (prm.zero_run && sh.best_hasrun) {
+                partition_fused<G, true>(th, sh, max_p, flush32);
+            } else if (prm.debug_skip & 32768u) {
+                partition_fused<G, false>(th, sh, max_p, flush32_nozr);  // (A/B: the plain walk)
+            } else {
+                // no sample walk where the Rice parameter is provably constant over the chunk; the other (chunk, order)
+                // pairs are queued and walked densely packed
+                // (per wave: no workgroup barrier, no atomic -- a wave's queue is filled and drained by the wave itself)
+                uint16_t* wq = &pm.queue[(tid >> 6) * 64 * G::MAXP];
+                uint32_t queued = 0;  // wave-uniform
+                partition_quick<G>(th, sh, max_p, flush32_nozr, [&](uint32_t entry, bool ambiguous) {
+                    const unsigned long long m = __ballot(ambiguous);
+                    if (ambiguous) wq[queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)entry;
+                    queued += (uint32_t)__popcll(m);
+                });
+                STAMP(7);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS stores, before it reads them back
+                for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) partition_slow_entry<G>(sh, n, wq[e], flush_entry);
+                STAMP(9);
+            }
         } else {
             for (int p = 1; p <= max_p; ++p) {
                 if (pnarrow) {
@@ -1199,10 +1276,18 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         STAMP(19);
         __syncthreads();
         STAMP(20);
-        for (int idx = tid; idx < nseg; idx += G::T) {
-            const int p = 31 - __clz(idx + 2);
-            const unsigned long long bits = seg_choose(sh, (uint32_t)idx, prm.zero_run);
-            atomicAdd(&pm.pbits[p], bits);
+        // Segment idx of order p has idx + 2 in [2^p, 2^(p+1)): walking j = idx + 2 in chunks of 64 gives every wave
+        // from j = 64 on segments of ONE order -- one atomic per wave there instead of 64 on one address.
+        for (int j0 = tid & ~63; j0 < nseg + 2; j0 += G::T) {  // wave-uniform trip count
+            const int j = j0 + (tid & 63), idx = j - 2;
+            const bool valid = j >= 2 && idx < nseg;
+            const unsigned long long bits = valid ? seg_choose(sh, (uint32_t)idx, prm.zero_run) : 0ull;
+            if (j0 >= 64) {
+                const unsigned long long sum = wave_sum_u64(bits);
+                if ((tid & 63) == 0) atomicAdd(&pm.pbits[31 - __clz(j0)], sum);
+            } else if (valid) {
+                atomicAdd(&pm.pbits[31 - __clz(j)], bits);
+            }
         }
         __syncthreads();
     }

@@ -21,19 +21,32 @@ def child(secs, kind, bd, sr):
     d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
     enc = lacx.Encoder(12, 2, sr, bd, device=0)
     layout = lacx.PCM_INTERLEAVED_I16 if bd == 16 else lacx.PCM_INTERLEAVED_I24
-    for _ in range(3):
+    ablation = bool(os.environ.get("LACX_DEBUG_SKIP"))  # timing ablations produce wrong plans: errors are expected
+
+    def once():
         enc.encode_shard_pcm_device_begin(d.data_ptr(), layout, 2, frames, 0)
-        pay, tab = enc.encode_shard_end()
+        try:
+            return enc.encode_shard_end()
+        except RuntimeError:
+            if not ablation:
+                raise
+            return None
+
+    for _ in range(3):
+        once()
     torch.cuda.synchronize()
     full, step = [], []
+    res = None
     for _ in range(10):
         t0 = time.perf_counter()
-        enc.encode_shard_pcm_device_begin(d.data_ptr(), layout, 2, frames, 0)
-        pay, tab = enc.encode_shard_end()
+        res = once()
         step.append((time.perf_counter() - t0) * 1e3)
         full.append(enc.timing().full_ms)
-    lac = lacx.assemble(sr, bd, 2, 2, [(pay.tobytes(), np.array(tab, dtype=np.uint32))])
-    sha = hashlib.sha256(lac).hexdigest()
+    sha = None
+    if res is not None:
+        pay, tab = res
+        lac = lacx.assemble(sr, bd, 2, 2, [(pay.tobytes(), np.array(tab, dtype=np.uint32))])
+        sha = hashlib.sha256(lac).hexdigest()
     with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
         dg = {(e["gen"]["frames"], e["gen"]["bit_depth"], e["gen"]["sample_rate"], e["gen"]["kind"], e["gen"]["seed"]): e for e in json.load(f)
               if e["gen"]["channels"] == 2 and e["stereo_mode"] == 2 and e["gen"].get("start", 0) == 0}
@@ -44,7 +57,7 @@ def child(secs, kind, bd, sr):
         import ctypes as C
         buf = (C.c_ulonglong * 40)()
         lacx.lib().lacx_debug_stamps(buf)
-        names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "-", "phase_a", "-", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish", "-"]
+        names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "part: quick", "phase_a", "part: queued", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish", "-"]
         idx = [i for i in range(32) if i != 22]
         tot = sum(buf[i] for i in idx)
         waves = max(1, buf[32])

@@ -8,6 +8,7 @@
 // lossless-audio-codec_amd/ links or loads it.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -117,11 +118,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         for (int t = 0; t < G::T; ++t) zr = zr || th[t].has4 != 0;
         zr = zr && zero_run;
         for (int t = 0; t < G::T; ++t) {
-            if (narrow) {
-                if (zr) phase_b<G, true, true>(th[t], sh, k0); else phase_b<G, true, false>(th[t], sh, k0);
-            } else {
-                if (zr) phase_b<G, false, true>(th[t], sh, k0); else phase_b<G, false, false>(th[t], sh, k0);
-            }
+            phase_b_dispatch<G>(th[t], sh, k0, narrow, zr, n == (uint32_t)G::MAXN);
             if ((uint32_t)th[t].a < n) {
                 sh.acc[0][0] += th[t].crice;
                 sh.acc[0][1] += th[t].cbin;
@@ -168,17 +165,28 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
             pm.segacc[idx][2] += zr;
             pm.segrun[idx] |= hr;
         };
+        auto flushq = [&](int, uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr, uint32_t hr) {
+            flush(idx, rc, bn, zr, hr);
+        };
         const bool fused = pnarrow && !(force_wide & 2) && partitions_chunk_aligned<G>(n, max_p);
+        const bool quick = fused && !(zero_run && sh.best_hasrun) && !(force_wide & 8);
+        pm.qcount = 0;
         for (int t = 0; t < G::T; ++t) {
+            if (quick) {  // the kernel's default: no sample walk where the Rice parameter is constant over the chunk
+                partition_quick<G>(th[t], sh, max_p, flushq, [&pm](uint32_t entry, bool ambiguous) { if (ambiguous) pm.queue[pm.qcount++] = (uint16_t)entry; });
+                continue;
+            }
             if (fused) {
-                if (zero_run && sh.best_hasrun) partition_fused<G, true>(th[t], sh, max_p, flush);
-                else partition_fused<G, false>(th[t], sh, max_p, flush);
+                if (zero_run && sh.best_hasrun) partition_fused<G, true>(th[t], sh, max_p, flushq);
+                else partition_fused<G, false>(th[t], sh, max_p, flushq);
                 continue;
             }
             for (int p = 1; p <= max_p; ++p) {
                 if (pnarrow) partition_pass<G, true>(th[t], sh, p, flush); else partition_pass<G, false>(th[t], sh, p, flush);
             }
         }
+        for (uint32_t e = 0; quick && e < pm.qcount; ++e) partition_slow_entry<G>(sh, n, pm.queue[e], flush);
+        if (quick && getenv("LACX_SIM_QSTATS")) fprintf(stderr, "quick: n=%u queued %u of %u\n", n, pm.qcount, (n / (uint32_t)G::CH) * (uint32_t)max_p);
         for (int p = 1; p <= max_p; ++p) {
             pm.pbits[p] = 0;
             const uint32_t segbase = (2u << (p - 1)) - 2u;
@@ -294,7 +302,8 @@ int sim_block_encode(const int32_t* x, uint32_t n, int zero_run, int partitionin
 
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
 // force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;
-// bit 1: use the per-order partition passes even where the fused pass applies; bit 2: no candidate pruning
+// bit 1: use the per-order partition passes even where the fused pass applies; bit 2: no candidate pruning;
+// bit 3: the fused walk instead of partition_quick
 int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
                    ChannelPlan* out) {
     if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);
