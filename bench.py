@@ -528,7 +528,7 @@ def worker(args) -> int:
 
     # ---- N = 1: the other single-GPU BASELINE configs, each verified against its reference-minted digest -----------
     # Outside the headline loop (never part of `value`): BASELINE configs[2] at its stated size (10 min stereo 24-bit 96 kHz,
-    # mixed material), one minute of white noise 16/48 (the hardest material: every block "uncertain", about five exactly
+    # mixed material), ten minutes of white noise 16/48 (the hardest material: every block "uncertain", about five exactly
     # costed candidates per slot) and BASELINE configs[4] (the 16 combinations {mono, stereo} x {16, 24 bit} x {44.1, 48,
     # 96, 192 kHz}, 60 s each) as ONE job.  A step = the whole job with its PCM resident in HBM in WAV layout, result in
     # pinned host memory; every .lac of the last step is compared with the golden digest minted from the reference
@@ -591,8 +591,8 @@ def worker(args) -> int:
 
         timed_job("BASELINE configs[2]: 10 min synthetic stereo 24-bit 96 kHz (mixed material), partitioning + zero-run on",
                   [("cfg3_10min_st24_96k_mixed", 57_600_000, 2, 24, 96000, 2, "mixed", "wide", 7)])
-        timed_job("white noise: 60 s synthetic stereo 16-bit 48 kHz, independent channels (every block uncertain)",
-                  [("noise_60s_st16_48k", 2_880_000, 2, 16, 48000, 2, "noise", "independent", 3)])
+        timed_job("white noise: 10 min synthetic stereo 16-bit 48 kHz, independent channels (every block uncertain)",
+                  [("noise_10min_st16_48k", 28_800_000, 2, 16, 48000, 2, "noise", "independent", 3)])
         cfg5 = []
         for ch in (1, 2):
             for bd in (16, 24):

@@ -20,6 +20,8 @@
  *   lacx_assemble          <- the block loop + block table concat of LAC::Encoder::encode, split so that
  *                             contiguous block ranges can be encoded by different GPUs/processes
  *                                                            ref lac/encoder.cpp:252-263, 445-465
+ *   lacx_encode_batch_device <- one LAC::Encoder::encode per file of a corpus, as one device job
+ *                                                            ref lac/encoder.cpp:215-466 (block pool :404-435)
  *   lacx_stream_parse /
  *   lacx_decode            <- LAC::Decoder::decode          ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
  *                                                            src/codec/block/decoder.cpp:64-520
@@ -98,7 +100,11 @@ typedef struct lacx_timing {
     double full_exec_ms;    /* device emit pipeline: k_analyze<16,1024> execution spans (first workgroup start to last
                                workgroup end, device clock), summed over its launches -- full_ms minus queueing */
     uint32_t emit_direct;   /* fused emit: channel blocks the streaming packer moved to the payload beside the analysis */
-    uint32_t emit_parked;   /* reserved */
+    uint32_t moved_by_k_pack; /* ... and those the repair kernel k_pack had to move afterwards (0 when the packer kept up) */
+    uint32_t packer_gave_up;  /* packer waves that stopped after 20 ms without an awaited record (0 normally; when the
+                                 packer cannot run beside the analysis -- a profiler that serialises kernels, a shared
+                                 GPU -- every wave gives up and k_pack moves everything: correct, but slower) */
+    uint32_t reserved0;
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);
@@ -174,6 +180,33 @@ int lacx_encode_shard_pcm_device_view(lacx_encoder* enc, const lacx_pcm* d_pcm, 
 int lacx_encode_shard_pcm_device_begin(lacx_encoder* enc, const lacx_pcm* d_pcm, uint64_t frames, void* stream);
 int lacx_encode_shard_end(lacx_encoder* enc, const uint8_t** payload, uint64_t* payload_size, const uint32_t** table,
                           uint32_t* nblocks);
+
+/* Many streams as ONE job (BASELINE configs[4]: a mixed corpus; the reference keeps one pool over all blocks of a stream,
+ * ref src/codec/lac/encoder.cpp:404-435 -- here the pool spans the blocks of all streams of the batch): one launch set
+ * over every block of every stream instead of one per stream, so that short streams do not each pay the chain
+ * ingest -> Levinson -> probes -> decision -> analysis by themselves.  Every stream keeps its own sample rate, bit depth,
+ * channel count, stereo mode and layout; zero-run / partitioning switches come from the encoder's config.  Device-
+ * resident PCM, device-side emit; out[i] views the stream's payload and block table inside the encoder's pinned result
+ * buffer (valid until the next call on the encoder); lacx_assemble turns (payload, table) into the stream's .lac, the
+ * bytes LAC::Encoder::encode gives for that stream alone.  Errors name the stream ("stream 3: left sample at index
+ * ... is outside ..."). */
+typedef struct lacx_batch_item {
+    lacx_pcm pcm;         /* device-resident PCM of the stream */
+    uint64_t frames;
+    uint32_t sample_rate; /* 44100 / 48000 / 96000 / 192000 */
+    uint8_t bit_depth;    /* 16 / 24 (an interleaved layout must match it) */
+    uint8_t stereo_mode;  /* 0 LR, 1 MS, 2 per-block auto (ignored for mono) */
+    uint8_t reserved[2];
+} lacx_batch_item;
+typedef struct lacx_batch_out {
+    const uint8_t* payload;
+    uint64_t payload_size;
+    const uint32_t* table; /* (frames, bytes) per block */
+    uint32_t nblocks;
+    uint32_t reserved;
+} lacx_batch_out;
+int lacx_encode_batch_device(lacx_encoder* enc, const lacx_batch_item* items, uint32_t nstreams, void* stream,
+                             lacx_batch_out* out);
 
 /* WAV ingest (replaces read_wav + LAC::Encoder::encode of the CLI's encode command,
  * ref src/io/wav_io.cpp:167-277, src/main.cpp:640-675).  lacx_wav_parse walks the RIFF container in memory and

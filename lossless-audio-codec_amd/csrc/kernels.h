@@ -32,7 +32,28 @@ struct DeviceWorkspace {
     uint32_t* packed = nullptr;               // 1: the streaming packer moved it to the payload
     unsigned long long* size_rec = nullptr;   // hand-off words of the fused emit (see kernels.hip)
     unsigned long long* ready_rec = nullptr;
+    unsigned long long* stream_pre = nullptr; // [streams] k_offsets: payload prefix at every stream's first block (sets of several streams)
 };
+
+// One launch set on the host: the kernel argument plus what the launchers themselves need to know.
+struct LaunchSet {
+    BatchRef br;
+    const StreamDesc* streams = nullptr;  // host copy of the descriptors (nstreams entries; &br.single for one stream)
+    uint32_t nstreams = 0;
+    uint32_t total_items = 0;             // channel blocks of the set = its stream indices
+    const uint16_t* item_stream = nullptr;  // device: the stream of every stream index (null for one stream)
+};
+// A set of one stream: the descriptor travels in the kernel arguments.
+inline LaunchSet single_set(const StreamDesc& sd) {
+    LaunchSet ls;
+    ls.br.table = nullptr;
+    ls.br.nstreams = 1;
+    ls.br.total_blocks = sd.prm.num_blocks;
+    ls.br.single = sd;
+    ls.nstreams = 1;
+    ls.total_items = sd.prm.num_blocks * (sd.prm.channels == 2 ? 2u : 1u);
+    return ls;  // (the caller points ls.streams at ls.br.single once the set has its final address)
+}
 
 // Where the whole-block analysis kernel writes a channel block's bitstream as soon as its plan is final (slots == null:
 // no fused emit; the bitstream then comes from k_offsets + k_emit alone).
@@ -43,7 +64,6 @@ struct FuseArgs {
     uint32_t* err_flag = nullptr;
     unsigned long long* size_rec = nullptr;   // per stream index: 1 << 62 | ms << 61 | bytes, once the plan is final
     unsigned long long* ready_rec = nullptr;  // per stream index: 1 slot published, 2 nothing will come
-    uint32_t fuse_items = 0;                  // stream indices below this one take part (a small final block does not)
 };
 
 // The small results the host reads after a call (block plans, block table, totals, flags, time stamps) go back in ONE
@@ -64,31 +84,31 @@ struct GatherList {
 };
 hipError_t launch_gather(const GatherList& g, hipStream_t stream);
 
-// Enqueues the whole analysis pipeline for one shard on `stream` (no host synchronisation).
+// Enqueues the whole analysis pipeline for one launch set on `stream` (no host synchronisation).
 // ev: optional 5 events recorded at: start, after ingest+levinson, after probes+decide, after the
 // whole-block analysis kernel, end.  wait_before_full: optional event the whole-block analysis kernel waits for.
-hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
+hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
                            const FuseArgs* fuse = nullptr, hipEvent_t wait_before_full = nullptr);
 
-// Device-side emit of the analysed blocks of one chunk into the shard payload: k_offsets (block byte offsets), k_pack
-// (channel blocks the fused emit left in their staging slots: ws.emitted set) and k_emit (all others).
+// Device-side emit of the analysed blocks of one set into the result buffer `out` (every stream at its
+// StreamDesc::out_base): k_offsets (block byte offsets), k_pack (channel blocks the fused emit left in their staging
+// slots: ws.emitted set) and k_emit (all others).
 // skip_emitted = false: k_emit emits everything (re-emit into a regrown buffer).
 // moved_total / shard_items: the streaming packer's count of channel blocks it has put in place and the number the shard
 // has; when they agree k_pack and k_emit have nothing to do and return at once (null: always look).
 // wait_before_pack: the packer's completion event; k_offsets does not depend on it and runs in front of the wait.
-hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                       const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
+// repacked (nullable): counts the channel blocks k_pack had to move.
+hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
                        hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted = true,
                        const uint32_t* moved_total = nullptr, uint32_t shard_items = 0,
-                       hipEvent_t wait_before_pack = nullptr);
+                       hipEvent_t wait_before_pack = nullptr, uint32_t* repacked = nullptr);
 
 // The streaming packer of the fused emit: runs beside the analysis kernels on its own stream and moves the staging
-// slots of stream indices [0, fuse_items) to their place in `out` as they are published.  err_flag[1] receives the
-// number of channel blocks it has put in place.
-hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
-                             unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream);
+// slots of the set's stream indices to their place in `out` as they are published.  counters: [0] error flags, [1] the
+// number of channel blocks it has put in place, [2] packer waves that gave up waiting for a record.
+hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
+                             hipStream_t stream);
 
 // The decoder (decode.hip): one lane per block; payload must be followed by kDecodeTailPad readable zero bytes (the bit
 // reader's bounded look-ahead past the last block, see BitIn).

@@ -292,6 +292,55 @@ __device__ __forceinline__ SlotGeom slot_geom(const AnalyzeParams& prm, uint32_t
     return g;
 }
 
+// The stream a global block of the launch set belongs to (StreamDesc, lacx_types.h): the descriptor in the kernel
+// arguments when the set is one stream, else a binary search over the table's first blocks (a handful of steps, the same
+// for every lane of a workgroup that works on one block).  Returned BY VALUE: the caller's copy lives in (scalar)
+// registers; a reference that may point at the kernel arguments or at the table made every later field access a memory
+// load (measured: +7 % on the whole-block analysis kernel).
+// A descriptor fetched from the table is the same in every lane of the wave (it only depends on the workgroup's block),
+// which the compiler cannot see through the search loop: without help it keeps the 26 words in vector registers and the
+// analysis kernel spills.  readfirstlane puts them where they belong.
+__device__ __forceinline__ StreamDesc wave_uniform(const StreamDesc& d) {
+    static_assert(sizeof(StreamDesc) % 4 == 0, "whole words");
+    StreamDesc r;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&d);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(StreamDesc) / 4; ++i) dst[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)src[i]);
+    return r;
+}
+
+__device__ __forceinline__ StreamDesc stream_of_block(const BatchRef& br, uint32_t gblk) {
+    if (br.table == nullptr) return br.single;
+    uint32_t lo = 0, hi = br.nstreams;  // invariant: table[lo].first_block <= gblk < table[hi].first_block
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (br.table[mid].first_block <= gblk) lo = mid; else hi = mid;
+    }
+    return wave_uniform(br.table[lo]);
+}
+// ... by workgroup of the whole-block analysis grid (channels per block: mono and stereo streams share the grid)
+__device__ __forceinline__ StreamDesc stream_of_workgroup(const BatchRef& br, uint32_t wg) {
+    if (br.table == nullptr) return br.single;
+    uint32_t lo = 0, hi = br.nstreams;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (br.table[mid].first_wg <= wg) lo = mid; else hi = mid;
+    }
+    return wave_uniform(br.table[lo]);
+}
+
+// ... by stream index (block * channels + channel over the set; prm.stream_base = the stream's first)
+__device__ __forceinline__ StreamDesc stream_of_item(const BatchRef& br, uint32_t item) {
+    if (br.table == nullptr) return br.single;
+    uint32_t lo = 0, hi = br.nstreams;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (br.table[mid].prm.stream_base <= item) lo = mid; else hi = mid;
+    }
+    return br.table[lo];
+}
+
 __device__ __forceinline__ SlotSrc slot_src(const AnalyzeParams& prm, const int32_t* L, const int32_t* R, int ch) {
     SlotSrc s;
     s.kind = ch;
@@ -365,9 +414,7 @@ __device__ __forceinline__ void xcd_slot(uint32_t w, uint32_t per, uint32_t nblo
     }
 }
 
-__global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __restrict__ L,
-                                                           const int32_t* __restrict__ R, AnalyzeParams prm,
-                                                           unsigned long long* __restrict__ sums,
+__global__ __launch_bounds__(kIngestThreads, 5) void k_ingest(BatchRef br, unsigned long long* __restrict__ sums,
                                                            uint32_t* __restrict__ badidx,
                                                            int64_t* __restrict__ acorr) {
     // One tile = 4096 samples = 16 consecutive samples per thread, kept in LDS as 4-sample groups in four planes:
@@ -380,8 +427,13 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     __shared__ unsigned long long s_ac[13];
     __shared__ unsigned long long s_sum[3];
     __shared__ unsigned int s_bad;
-    uint32_t blk, chsel;
+    uint32_t blk, chsel;  // blk: global block of the launch set (indexes the workspace)
     xcd_slot(blockIdx.x, 4u, gridDim.x >> 2, blk, chsel);
+    const StreamDesc sd = stream_of_block(br, blk);
+    const AnalyzeParams prm = sd.prm;
+    const int32_t* __restrict__ L = sd.left;
+    const int32_t* __restrict__ R = sd.right;
+    const uint32_t lblk = blk - sd.first_block;  // the stream's own block number (geometry, sample addresses)
     const int ch = (int)chsel;
     const bool used = slot_channel_used(prm, ch);
     // forced mid/side still validates the left/right samples (ref lac/encoder.cpp:238-241)
@@ -393,8 +445,8 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nb = block_frames(prm, blk);
-    const int64_t bstart = (int64_t)blk * kMaxBlock;
+    const uint32_t nb = block_frames(prm, lblk);
+    const int64_t bstart = (int64_t)lblk * kMaxBlock;
     const SlotSrc src = slot_src(prm, L, R, ch);
     const bool est = prm.channels == 2 && prm.stereo_mode == 2;
     const int32_t lo = prm.bit_depth == 16 ? -32768 : -0x800000;
@@ -478,7 +530,7 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
     if (est && nb > (uint32_t)kFullCompareLimit) {
         if (tid < 36) s_win[tid / 12][tid % 12] = 0;  // the samples before a window count as absent
         for (int w = 1; w <= 3; ++w) {
-            const SlotGeom g = slot_geom(prm, blk, w * 4 + ch);
+            const SlotGeom g = slot_geom(prm, lblk, w * 4 + ch);
             s_win[w - 1][12 + tid] = slot_fetch(src, g.start + tid);  // kIngestThreads == kProbe
         }
         __syncthreads();
@@ -528,13 +580,15 @@ __global__ __launch_bounds__(kIngestThreads) void k_ingest(const int32_t* __rest
 // Sixteen lanes per block, four blocks per wave: lanes 0..11 of a block turn one of its 12 proxy sums into bits (one
 // 64-bit division each instead of a chain of twelve), lane 0 of the block decides.
 constexpr int kStereoLanes = 16;
-__global__ __launch_bounds__(64) void k_stereo(AnalyzeParams prm, const unsigned long long* __restrict__ sums,
+__global__ __launch_bounds__(64) void k_stereo(BatchRef br, const unsigned long long* __restrict__ sums,
                                                const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
                                                uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
     const int tid = threadIdx.x, sub = tid & (kStereoLanes - 1), grp = tid & ~(kStereoLanes - 1);
     const uint32_t blk = blockIdx.x * (64 / kStereoLanes) + (uint32_t)(tid / kStereoLanes);
-    const bool live = blk < prm.num_blocks;  // every lane stays for the shuffles
-    const uint32_t nb = live ? block_frames(prm, blk) : 0u;
+    const bool live = blk < br.total_blocks;  // every lane stays for the shuffles
+    const StreamDesc sd = stream_of_block(br, live ? blk : 0u);
+    const AnalyzeParams prm = sd.prm;
+    const uint32_t nb = live ? block_frames(prm, blk - sd.first_block) : 0u;
     const bool stereo = prm.channels == 2;
     const bool est = stereo && prm.stereo_mode == 2;
     // estimate_channel_proxy_cost: ref lac/encoder.cpp:114-124 -- sums[blk][kind * 4 + channel], kind = raw, diff, anti
@@ -608,17 +662,19 @@ struct LevMem {  // work arrays R, a, prevA of every thread, one column per thre
 // thread's latency whatever the grid looks like.  What the grid decides is how many CUs it takes away from the
 // other pipeline chunks' kernels meanwhile: slots are numbered slot-major (waves made of probe slots of certain
 // blocks leave at once) and packed 256 to a workgroup.
-__global__ __launch_bounds__(kLevThreads) void k_levinson(AnalyzeParams prm, const int64_t* __restrict__ acorr,
+__global__ __launch_bounds__(kLevThreads) void k_levinson(BatchRef br, const int64_t* __restrict__ acorr,
                                                           const uint32_t* __restrict__ need_probe,
                                                           LpcSet* __restrict__ lpcs) {
     extern __shared__ __align__(16) unsigned char lev_raw[];
     LevMem& lm = *reinterpret_cast<LevMem*>(lev_raw);
     const uint32_t id = blockIdx.x * kLevThreads + threadIdx.x;
-    const uint32_t nblk = prm.num_blocks;
+    const uint32_t nblk = br.total_blocks;
     const int slot = (int)(id / nblk);
     const uint32_t blk = id % nblk;
     if (slot >= kSlotsPerBlock) return;
-    const SlotGeom g = slot_geom(prm, blk, slot);
+    const StreamDesc sd = stream_of_block(br, blk);
+    const AnalyzeParams prm = sd.prm;
+    const SlotGeom g = slot_geom(prm, blk - sd.first_block, slot);
     if (!g.defined) return;
     if (prm.channels == 2 && slot < 4) {
         if (prm.stereo_mode == 0 && (slot & 3) >= 2) return;
@@ -829,7 +885,8 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
 // byte offset and copies slot after slot to its place in the payload (pinned host memory: the bytes cross PCIe while
 // later blocks are still being analysed, nothing is left to copy when the analysis ends).
 // Hand-off per stream index i (= block * channels + channel), two 8-byte words, each written by ONE agent-scope store:
-//   size_rec[i]  = 1 << 62 | ms << 61 | bytes     as soon as the plan is final (the data is the flag: R2 granule of
+//   size_rec[i]  = 1 << 62 | ms << 61 | flag byte in front << 60 | bytes
+//                                                 as soon as the plan is final (the data is the flag: R2 granule of
 //                                                 MI355X_MICROARCH.md, no fence needed)
 //   ready_rec[i] = 1  the bitstream is in slot i: the slot is written with write-through (sc1) stores and announced
 //                     behind every storing wave's s_waitcnt vmcnt(0) and the workgroup barrier (cdna_hip_programming.md,
@@ -839,7 +896,7 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
 // Every wait of the packer is bounded; when it gives up, or for anything it did not move, k_pack / k_emit finish the
 // job after the analysis (they always run), so no dispatch order or co-residency is assumed for correctness.
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned long long kRecValid = 1ull << 62, kRecMs = 1ull << 61, kRecBytesMask = (1ull << 61) - 1ull;
+constexpr unsigned long long kRecValid = 1ull << 62, kRecMs = 1ull << 61, kRecFlag = 1ull << 60, kRecBytesMask = (1ull << 60) - 1ull;
 
 __device__ __forceinline__ unsigned long long rec_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -859,7 +916,7 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     asm volatile("" : "+v"(th.tid), "+v"(th.a));
     const unsigned long long my_size = (unsigned long long)sh.plan.payload_bytes + (flag_byte ? 1u : 0u);
     // the size is final: publish it at once (the packer can account for this block while it is being emitted)
-    if (tid == 0) rec_store(&fa.size_rec[idx], kRecValid | (flag_value ? kRecMs : 0ull) | my_size);
+    if (tid == 0) rec_store(&fa.size_rec[idx], kRecValid | (flag_value ? kRecMs : 0ull) | (flag_byte ? kRecFlag : 0ull) | my_size);
     // a bitstream longer than the slot (never seen: it would take > 3 resp. 5 bytes per sample) is left to k_emit;
     // test hook (LACX_DEBUG_SKIP bit 10): so is every fifth channel block
     const bool skip = (unsigned long long)sh.plan.payload_bytes + 16u > fa.slot_stride ||
@@ -1317,8 +1374,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 // streaming packer takes a whole CU away from the analysis: measured +25 us of kernel time per packer workgroup, hence
 // the packer's small grid.  The compiler offers no way to cap this kernel at 120.)
 template <class G>
-__global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
-                                                  AnalyzeParams prm, int probe_class, uint32_t blk_offset,
+__global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans,
@@ -1329,21 +1385,33 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(const int3
     // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
     if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
-    // should be one that has work.  Whole-block class: workgroup w analyses the (w % per + which_base)-th
-    // needed slot of block w / per.  Probe class: 12 slots per block, skipped unless the block is uncertain.
-    uint32_t blk;
+    // should be one that has work.  Whole-block class: the stream's workgroup w analyses the (w % per)-th needed slot of
+    // its block w / per (per = the stream's channels; the streams of a set follow each other in the grid).  Probe class:
+    // 12 slots per block, skipped unless the block is uncertain.  which_base != 0: the two extra workgroups of ONE block
+    // (global block one_block) whose four channels are all needed.
+    uint32_t blk;  // global block of the launch set
     int slot = -1;
     int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
     uint32_t needed_slots = 0;
+    StreamDesc sd;
     if (probe_class) {
         blk = blockIdx.x / 12u;
+        sd = stream_of_block(br, blk);
         const int s = 4 + (int)(blockIdx.x % 12u);
         if ((need[blk] >> s) & 1u) slot = s;
     } else {
-        const uint32_t per = prm.channels == 2 ? 2u : 1u;
         uint32_t wsel;
-        xcd_slot(blockIdx.x, per, (prm.debug_skip & 512u) ? 0u : gridDim.x / per, blk, wsel);
-        blk += blk_offset;
+        if (which_base) {
+            blk = one_block;
+            sd = stream_of_block(br, blk);
+            wsel = blockIdx.x;
+        } else {
+            sd = stream_of_workgroup(br, blockIdx.x);
+            const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
+            uint32_t lblk;
+            xcd_slot(blockIdx.x - sd.first_wg, per, (sd.prm.debug_skip & 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
+            blk = sd.first_block + lblk;
+        }
         int which = (int)wsel + which_base;
         which_in_block = which;
         uint32_t m = need[blk] & 0xFu;
@@ -1359,20 +1427,23 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(const int3
         }
     }
     if (slot < 0) return;  // uniform for the workgroup
-    const SlotGeom g = slot_geom(prm, blk, slot);
+    const AnalyzeParams prm = sd.prm;
+    const uint32_t lblk = blk - sd.first_block;
+    const SlotGeom g = slot_geom(prm, lblk, slot);
     const uint32_t n = g.n;
     const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
-    const SlotSrc src = slot_src(prm, L, R, slot & 3);
+    const SlotSrc src = slot_src(prm, sd.left, sd.right, slot & 3);
 
     // Fused emit: only where the block's channel pair is already final, i.e. exactly `channels` whole-block slots are
     // needed (a small final block that is encoded both ways and compared afterwards is left to k_emit).
     long long fuse_idx = -1;
     bool flag_byte = false;
-    if (fuse.slots && !probe_class) {
-        fuse_idx = (long long)prm.stream_base + ((long long)blk - (long long)blk_offset) * prm.channels + which_in_block;
+    if (fuse.slots && !probe_class && !which_base) {
+        const uint32_t item = lblk * (uint32_t)prm.channels + (uint32_t)which_in_block;  // within the stream
+        fuse_idx = (long long)prm.stream_base + item;
         flag_byte = prm.channels == 2 && prm.stereo_mode == 2 && which_in_block == 0;
         // the host excludes a small final block that may be encoded both ways and compared afterwards (fuse_items)
-        if (fuse_idx >= (long long)fuse.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
+        if (item >= sd.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
     }
     analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid, fuse, fuse_idx, flag_byte,
                     (uint32_t)((slot & 3) >= 2 ? 1u : 0u));
@@ -1382,15 +1453,16 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(const int3
 // ---------------------------------------------------------------------------------------------
 // k_decide
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, BlockPlan* __restrict__ bplans,
+__global__ __launch_bounds__(64) void k_decide(BatchRef br, int phase, BlockPlan* __restrict__ bplans,
                                                const uint32_t* __restrict__ need_probe,
                                                uint32_t* __restrict__ need_full,
                                                const ChannelPlan* __restrict__ plans) {
     // sixteen lanes per block, lane s reads slot s's size: one round of loads instead of twelve dependent cache misses
     const int tid = threadIdx.x, sub = tid & 15;
     const uint32_t blk = blockIdx.x * 4u + (uint32_t)(tid >> 4);
-    if (prm.channels != 2 || prm.stereo_mode != 2) return;  // uniform
-    const bool live = blk < prm.num_blocks;
+    // (only blocks of per-block-stereo streams are ever marked uncertain: k_stereo)
+    if (br.table == nullptr && (br.single.prm.channels != 2 || br.single.prm.stereo_mode != 2)) return;  // uniform
+    const bool live = blk < br.total_blocks;
     BlockPlan bp{};
     if (live) bp = bplans[blk];
     const bool mine = live && bp.uncertain &&
@@ -1415,31 +1487,37 @@ __global__ __launch_bounds__(64) void k_decide(AnalyzeParams prm, int phase, Blo
 // device-side emit: k_offsets + k_emit
 // ---------------------------------------------------------------------------------------------
 // One workgroup: byte size of every block's payload ([flag] + the two chosen channel blocks), exclusive
-// prefix -> block_off[0..nb], and the container's block table entries (frames, bytes).
-__global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+// prefix -> block_off[0..nb] (byte offset of the block in the result buffer), and the container's block table entries
+// (frames, bytes).  In a set of several streams every stream's payload starts at its own region (StreamDesc::out_base):
+// stream_pre[s] receives the prefix at the stream's first block and the offsets are re-based per stream.
+__global__ __launch_bounds__(1024) void k_offsets(BatchRef br, const BlockPlan* __restrict__ bplans,
                                                    const ChannelPlan* __restrict__ plans,
                                                    unsigned long long* __restrict__ block_off,
                                                    uint32_t* __restrict__ table,
-                                                   const unsigned long long* __restrict__ base_ptr) {
+                                                   const unsigned long long* __restrict__ base_ptr,
+                                                   unsigned long long* __restrict__ stream_pre) {
     __shared__ unsigned long long s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nb = prm.num_blocks;
+    const uint32_t nb = br.total_blocks;
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = (uint32_t)tid * per;
-    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     unsigned long long sum = 0;
+    constexpr uint32_t kKeep = 8;  // block sizes kept in registers for the second pass (shards up to 8192 blocks)
+    uint32_t kept[kKeep];
+#pragma unroll
+    for (uint32_t k = 0; k < kKeep; ++k) kept[k] = 0;
     for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
+        const AnalyzeParams prm = stream_of_block(br, b).prm;
+        const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
         const ChannelPlan* p = plans + (size_t)b * kSlotsPerBlock;
-        uint32_t bytes;
-        if (prm.channels == 1) {
-            bytes = p[CH_L].payload_bytes;
-        } else {
-            const bool ms = bplans[b].choose_ms != 0;
-            bytes = (ms ? p[CH_M].payload_bytes + p[CH_S].payload_bytes : p[CH_L].payload_bytes + p[CH_R].payload_bytes) +
-                    (autost ? 1u : 0u);
-        }
-        table[2 * b] = bplans[b].frames;
+        // every size the block could need, fetched at once (the kernel is one latency chain: no load waits for another)
+        const uint32_t sl = p[CH_L].payload_bytes, sr = p[CH_R].payload_bytes, sm = p[CH_M].payload_bytes, ss = p[CH_S].payload_bytes;
+        const BlockPlan bp = bplans[b];
+        const bool ms = bp.choose_ms != 0;
+        const uint32_t bytes = prm.channels == 1 ? sl : ((ms ? sm + ss : sl + sr) + (autost ? 1u : 0u));
+        table[2 * b] = bp.frames;
         table[2 * b + 1] = bytes;
+        if (b - b0 < kKeep) kept[b - b0] = bytes;
         sum += bytes;
     }
     const unsigned long long inc = wave_scan_add_u64(sum);
@@ -1450,31 +1528,51 @@ __global__ __launch_bounds__(1024) void k_offsets(AnalyzeParams prm, const Block
     unsigned long long run = base + inc - sum;
     for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
         block_off[b] = run;
-        run += table[2 * b + 1];
+        uint32_t bytes = 0;
+        if (b - b0 < kKeep) {
+#pragma unroll
+            for (uint32_t k = 0; k < kKeep; ++k) bytes = (b - b0 == k) ? kept[k] : bytes;
+        } else {
+            bytes = table[2 * b + 1];
+        }
+        run += bytes;
     }
     if (tid == 1023) block_off[nb] = base + inc;
+    if (br.table != nullptr) {  // uniform
+        __syncthreads();  // (block_off is global memory written by this workgroup: visible to it after the barrier)
+        for (uint32_t sidx = (uint32_t)tid; sidx < br.nstreams; sidx += 1024u) stream_pre[sidx] = block_off[br.table[sidx].first_block];
+        __syncthreads();
+        for (uint32_t b = b0; b < b0 + per && b < nb; ++b) {
+            const StreamDesc sd = stream_of_block(br, b);
+            block_off[b] = block_off[b] - stream_pre[sd.pad] + sd.out_base;  // (pad = the stream's number in a table)
+        }
+    }
 }
 
 // One channel block of k_emit (workgroup-uniform control flow throughout).
 template <class G>
-__device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx, const int32_t* __restrict__ L,
-                                                   const int32_t* __restrict__ R, const AnalyzeParams& prm,
+__device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx, const StreamDesc& sd,
                                                    const BlockPlan* __restrict__ bplans,
                                                    const ChannelPlan* __restrict__ plans,
                                                    const unsigned long long* __restrict__ block_off,
-                                                   uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                   const uint32_t* __restrict__ table,
+                                                   uint8_t* __restrict__ out,
                                                    uint32_t* __restrict__ err_flag, uint32_t blk, int which, int tid) {
     asm volatile("" : "+v"(tid));  // nothing derived from the thread index is hoisted out of the caller's loop (spills)
+    const AnalyzeParams prm = sd.prm;
+    const int32_t* __restrict__ L = sd.left;
+    const int32_t* __restrict__ R = sd.right;
+    const uint32_t lblk = blk - sd.first_block;
     const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
     const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
     const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
     const int kind = which == 0 ? first_kind : (ms ? CH_S : CH_R);
     const ChannelPlan* plan = plans + (size_t)blk * kSlotsPerBlock + kind;
-    const uint32_t n = block_frames(prm, blk);
+    const uint32_t n = block_frames(prm, lblk);
     unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
     if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
     // the destination is sized from an estimate: if this block does not fit, report it and write nothing
-    if (block_off[blk + 1] > out_cap) {
+    if (block_off[blk] + table[2 * blk + 1] > sd.out_base + sd.out_cap) {
         if (tid == 0) atomicOr(err_flag, 2u);
         return;
     }
@@ -1482,7 +1580,7 @@ __device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx
 
     Thread<G> th;
     thread_init(th, n, tid);
-    stage_samples(th, sh, slot_src(prm, L, R, kind), (int64_t)blk * kMaxBlock);
+    stage_samples(th, sh, slot_src(prm, L, R, kind), (int64_t)lblk * kMaxBlock);
     emit_load_plan(sh, *plan, tid, G::T);
     if (tid == 0 && !plan->valid) sh.err = 1;
     __syncthreads();
@@ -1507,11 +1605,11 @@ __device__ __forceinline__ void emit_channel_block(EmitMem<G>& sh, int32_t* s_wx
 // in k_analyze); behind the fused emit the launcher uses a small grid that strides over the chunk, because then there
 // is normally nothing left to do and a full grid of 1024-thread workgroups that exit at once is pure launch time.
 template <class G>
-__global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, const int32_t* __restrict__ R,
-                                               AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+__global__ __launch_bounds__(G::T) void k_emit(BatchRef br, uint32_t total_items, const BlockPlan* __restrict__ bplans,
                                                const ChannelPlan* __restrict__ plans,
                                                const unsigned long long* __restrict__ block_off,
-                                               uint8_t* __restrict__ out, unsigned long long out_cap,
+                                               const uint32_t* __restrict__ table,
+                                               uint8_t* __restrict__ out,
                                                uint32_t* __restrict__ err_flag,
                                                const uint32_t* __restrict__ emitted,
                                                const uint32_t* __restrict__ moved_total, uint32_t shard_items) {
@@ -1520,13 +1618,22 @@ __global__ __launch_bounds__(G::T) void k_emit(const int32_t* __restrict__ L, co
     EmitMem<G>& sh = *reinterpret_cast<EmitMem<G>*>(smem_raw);
     __shared__ int32_t s_wx[16];
     const int tid = threadIdx.x;
-    const uint32_t per = prm.channels == 2 ? 2u : 1u;
-    const uint32_t total = prm.num_blocks * per;
-    for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
-        uint32_t blk, wsel;
-        xcd_slot(w, per, gridDim.x == total ? total / per : 0u, blk, wsel);
-        if (emitted && emitted[(size_t)prm.stream_base + (size_t)blk * per + wsel]) continue;  // uniform
-        emit_channel_block<G>(sh, s_wx, L, R, prm, bplans, plans, block_off, out, out_cap, err_flag, blk, (int)wsel, tid);
+    // items = channel blocks of the launch set in stream-index order, numbered from the set's first stream index
+    const uint32_t item0 = br.table ? br.table[0].prm.stream_base : br.single.prm.stream_base;
+    for (uint32_t w = blockIdx.x; w < total_items; w += gridDim.x) {
+        uint32_t item = w;
+        if (br.table == nullptr && gridDim.x == total_items) {  // one stream, full grid: the XCD-aware mapping of k_analyze
+            const uint32_t per = br.single.prm.channels == 2 ? 2u : 1u;
+            uint32_t b, wsel;
+            xcd_slot(w, per, total_items / per, b, wsel);
+            item = b * per + wsel;
+        }
+        const StreamDesc sd = stream_of_item(br, item0 + item);
+        const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
+        const uint32_t local = item0 + item - sd.prm.stream_base;
+        const uint32_t blk = sd.first_block + local / per, wsel = local % per;
+        if (emitted && emitted[(size_t)item0 + item]) continue;  // uniform
+        emit_channel_block<G>(sh, s_wx, sd, bplans, plans, block_off, table, out, err_flag, blk, (int)wsel, tid);
         __syncthreads();  // the LDS image is reused by the next channel block
     }
 }
@@ -1579,20 +1686,32 @@ __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, u
 constexpr int kStreamGrid = 2;
 constexpr int kStreamThreads = 1024;
 constexpr unsigned long long kStreamTimeoutTicks = 2000000ull;  // 20 ms of the 100 MHz clock without the awaited record
-__global__ __launch_bounds__(kStreamThreads) void k_stream_out(uint32_t total, int autost, int nap,
+__global__ __launch_bounds__(kStreamThreads) void k_stream_out(BatchRef br, uint32_t total, int nap,
+                                                               const uint16_t* __restrict__ item_stream,
                                                                const unsigned long long* __restrict__ size_rec,
                                                                const unsigned long long* __restrict__ ready_rec,
                                                                const uint8_t* __restrict__ slots, unsigned long long slot_stride,
-                                                               uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                               uint8_t* __restrict__ out,
                                                                uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag,
-                                                               uint32_t* __restrict__ moved_total) {
+                                                               uint32_t* __restrict__ moved_total, uint32_t* __restrict__ gave_up) {
+    // total: stream indices of the set (all streams).  In a set of several streams every stream's payload has its own
+    // region of the result buffer and its own running offset; item_stream[i] = the stream of index i (null: one stream).
     const int lane = threadIdx.x & 63;
     const uint32_t unit = blockIdx.x * (uint32_t)(kStreamThreads / 64) + (threadIdx.x >> 6);
     const uint32_t units = gridDim.x * (uint32_t)(kStreamThreads / 64);
-    unsigned long long running = 0;  // bytes of the stream indices [0, summed)
-    uint32_t summed = 0;
+    unsigned long long running = 0;  // bytes of the stream indices [first index of the current stream, summed)
+    uint32_t summed = br.table ? 0u : br.single.prm.stream_base;
+    uint32_t cur_first = summed;     // first stream index of the stream `running` belongs to
     uint32_t moved = 0;  // stream indices this wave has put in place
     for (uint32_t i = unit; i < total; i += units) {
+        const StreamDesc sd = br.table ? br.table[item_stream[i]] : br.single;
+        const uint32_t first = sd.prm.stream_base;
+        if (i - first >= sd.fuse_items) continue;  // left to k_emit (a small final block that is encoded both ways)
+        if (first != cur_first) {  // a new stream: its offsets start over in its own region
+            cur_first = first;
+            summed = first;
+            running = 0;
+        }
         bool alive = true;
         unsigned long long mine = 0;
         // sizes of [summed, i], 64 records per round; the last one is this index's own
@@ -1631,19 +1750,23 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream_out(uint32_t total, i
                 for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(16);
             }
         }
-        if (!alive) break;  // wave-uniform: a producer went missing; k_pack / k_emit move what is left
+        if (!alive) {  // wave-uniform: a producer went missing; k_pack / k_emit move what is left
+            if (lane == 0) atomicAdd(gave_up, 1u);
+            break;
+        }
         const unsigned long long off = running, rec = mine;
         running += mine & kRecBytesMask;  // this index is accounted for whatever happens to its bytes
         if (ready == 1ull) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const unsigned long long bytes = rec & kRecBytesMask;
-            const bool flag_byte = autost && (i & 1u) == 0u;
-            if (off + bytes > out_cap) {  // the destination was sized from an estimate: report, write nothing
+            const bool flag_byte = (rec & kRecFlag) != 0ull;
+            if (off + bytes > sd.out_cap) {  // the destination was sized from an estimate: report, write nothing
                 if (lane == 0) atomicOr(err_flag, 2u);
             } else {
-                if (flag_byte && lane == 0) out[off] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+                uint8_t* dst = out + sd.out_base + off;
+                if (flag_byte && lane == 0) dst[0] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
                 const uint32_t fb = flag_byte ? 1u : 0u;
-                copy_slot_out<64, LACX_STREAM_UNROLL>(slots + (unsigned long long)i * slot_stride, out + off + fb, (uint32_t)bytes - fb, lane);
+                copy_slot_out<64, LACX_STREAM_UNROLL>(slots + (unsigned long long)i * slot_stride, dst + fb, (uint32_t)bytes - fb, lane);
                 if (lane == 0) packed[i] = 1u;
                 ++moved;
             }
@@ -1659,37 +1782,44 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream_out(uint32_t total, i
 // small (kPackGrid workgroups striding over the channel blocks): a grid of one workgroup per channel block would fill
 // every wave slot of the chip with waves that wait for PCIe and lock the next chunk's analysis kernel out.
 constexpr int kPackGrid = 96;
-__global__ __launch_bounds__(kPackThreads) void k_pack(AnalyzeParams prm, const BlockPlan* __restrict__ bplans,
+__global__ __launch_bounds__(kPackThreads) void k_pack(BatchRef br, uint32_t total_items, const BlockPlan* __restrict__ bplans,
                                                        const ChannelPlan* __restrict__ plans,
                                                        const unsigned long long* __restrict__ block_off,
-                                                       uint8_t* __restrict__ out, unsigned long long out_cap,
+                                                       const uint32_t* __restrict__ table,
+                                                       uint8_t* __restrict__ out,
                                                        uint32_t* __restrict__ err_flag, const uint8_t* __restrict__ slots,
                                                        unsigned long long slot_stride,
                                                        const uint32_t* __restrict__ emitted,
                                                        const uint32_t* __restrict__ packed,
-                                                       const uint32_t* __restrict__ moved_total, uint32_t shard_items) {
+                                                       const uint32_t* __restrict__ moved_total, uint32_t shard_items,
+                                                       uint32_t* __restrict__ repacked) {
     if (moved_total && *moved_total == shard_items) return;  // the streaming packer has moved everything (uniform)
     const int tid = threadIdx.x;
-    const uint32_t per = prm.channels == 2 ? 2u : 1u;
-    for (uint32_t work = blockIdx.x; work < prm.num_blocks * per; work += gridDim.x) {
-    const uint32_t blk = work / per;
-    const int which = (int)(work % per);
-    const size_t idx = (size_t)prm.stream_base + work;
-    if (emitted[idx] != 2u || (packed && packed[idx])) continue;  // not in its slot (k_emit's job) / moved by the packer
-    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
-    const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
-    const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
-    const int kind = which == 0 ? first_kind : (ms ? CH_S : CH_R);
-    const uint32_t count = plans[(size_t)blk * kSlotsPerBlock + kind].payload_bytes;
-    unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
-    if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
-    // the destination is sized from an estimate: if this block does not fit, report it and write nothing
-    if (block_off[blk + 1] > out_cap) {
-        if (tid == 0) atomicOr(err_flag, 2u);
-        continue;
-    }
-    if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
-    copy_slot_out(slots + idx * slot_stride, out + off, count, tid);
+    const uint32_t item0 = br.table ? br.table[0].prm.stream_base : br.single.prm.stream_base;
+    for (uint32_t work = blockIdx.x; work < total_items; work += gridDim.x) {
+        const size_t idx = (size_t)item0 + work;
+        if (emitted[idx] != 2u || (packed && packed[idx])) continue;  // not in its slot (k_emit's job) / moved by the packer
+        const StreamDesc sd = stream_of_item(br, (uint32_t)idx);
+        const AnalyzeParams prm = sd.prm;
+        const uint32_t per = prm.channels == 2 ? 2u : 1u;
+        const uint32_t local = (uint32_t)idx - prm.stream_base;
+        const uint32_t blk = sd.first_block + local / per;
+        const int which = (int)(local % per);
+        const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
+        const bool ms = prm.channels == 2 && bplans[blk].choose_ms != 0;
+        const int first_kind = prm.channels == 1 ? CH_L : (ms ? CH_M : CH_L);
+        const int kind = which == 0 ? first_kind : (ms ? CH_S : CH_R);
+        const uint32_t count = plans[(size_t)blk * kSlotsPerBlock + kind].payload_bytes;
+        unsigned long long off = block_off[blk] + (autost ? 1u : 0u);
+        if (which == 1) off += plans[(size_t)blk * kSlotsPerBlock + first_kind].payload_bytes;
+        // the destination is sized from an estimate: if this block does not fit, report it and write nothing
+        if (block_off[blk] + table[2 * blk + 1] > sd.out_base + sd.out_cap) {
+            if (tid == 0) atomicOr(err_flag, 2u);
+            continue;
+        }
+        if (which == 0 && autost && tid == 0) out[block_off[blk]] = ms ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
+        copy_slot_out(slots + idx * slot_stride, out + off, count, tid);
+        if (tid == 0 && repacked) atomicAdd(repacked, 1u);
     }
 }
 
@@ -1753,21 +1883,20 @@ static hipError_t ensure_kernel_attrs() {
     return e;
 }
 
-hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                       const DeviceWorkspace& ws, uint8_t* out, unsigned long long out_cap,
+hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
                        hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted, const uint32_t* moved_total,
-                       uint32_t shard_items, hipEvent_t wait_before_pack) {
+                       uint32_t shard_items, hipEvent_t wait_before_pack, uint32_t* repacked) {
     const hipError_t attr_err = ensure_kernel_attrs();
     if (attr_err != hipSuccess) return attr_err;
-    const uint32_t nb = prm.num_blocks;
+    const uint32_t nb = ls.br.total_blocks;
     if (nb == 0) return hipSuccess;
     if (wait_before_offsets) {
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_offsets, 0);
         if (we != hipSuccess) return we;
     }
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, stream, prm, ws.bplans, ws.plans, ws.block_off, ws.table,
-                       base_ptr);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, stream, ls.br, ws.bplans, ws.plans, ws.block_off, ws.table,
+                       base_ptr, ws.stream_pre);
     if (offsets_done) {
         const hipError_t re = hipEventRecord(offsets_done, stream);
         if (re != hipSuccess) return re;
@@ -1776,17 +1905,16 @@ hipError_t launch_emit(const int32_t* d_left, const int32_t* d_right, const Anal
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_pack, 0);
         if (we != hipSuccess) return we;
     }
+    const uint32_t work = ls.total_items;
     if (skip_emitted && ws.slots) {
-        const uint32_t work = nb * (prm.channels == 2 ? 2u : 1u);
-        hipLaunchKernelGGL(k_pack, dim3(work < (uint32_t)kPackGrid ? work : (uint32_t)kPackGrid), dim3(kPackThreads), 0, stream, prm, ws.bplans,
-                           ws.plans, ws.block_off, out, out_cap, ws.err_flag, (const uint8_t*)ws.slots, ws.slot_stride,
-                           (const uint32_t*)ws.emitted, (const uint32_t*)ws.packed, moved_total, shard_items);
+        hipLaunchKernelGGL(k_pack, dim3(work < (uint32_t)kPackGrid ? work : (uint32_t)kPackGrid), dim3(kPackThreads), 0, stream, ls.br, work,
+                           ws.bplans, ws.plans, ws.block_off, (const uint32_t*)ws.table, out, ws.err_flag, (const uint8_t*)ws.slots,
+                           ws.slot_stride, (const uint32_t*)ws.emitted, (const uint32_t*)ws.packed, moved_total, shard_items, repacked);
     }
-    const uint32_t emit_work = nb * (prm.channels == 2 ? 2u : 1u);
     const bool leftovers_only = skip_emitted && ws.slots;  // behind the fused emit
-    hipLaunchKernelGGL(k_emit<GFull>, dim3(leftovers_only && emit_work > 64u ? 64u : emit_work), dim3(GFull::T),
-                       sizeof(EmitMem<GFull>), stream, d_left, d_right, prm, ws.bplans, ws.plans, ws.block_off,
-                       out, out_cap, ws.err_flag, skip_emitted ? (const uint32_t*)ws.emitted : (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(k_emit<GFull>, dim3(leftovers_only && work > 64u ? 64u : work), dim3(GFull::T),
+                       sizeof(EmitMem<GFull>), stream, ls.br, work, ws.bplans, ws.plans, ws.block_off, (const uint32_t*)ws.table,
+                       out, ws.err_flag, skip_emitted ? (const uint32_t*)ws.emitted : (const uint32_t*)nullptr,
                        leftovers_only ? moved_total : (const uint32_t*)nullptr, shard_items);
     return hipGetLastError();
 }
@@ -1800,42 +1928,51 @@ hipError_t launch_gather(const GatherList& g, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_stream_out(uint32_t fuse_items, int autost, const DeviceWorkspace& ws, uint8_t* out,
-                             unsigned long long out_cap, uint32_t* err_flag, hipStream_t stream) {
-    if (fuse_items == 0) return hipSuccess;
+hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
+                             hipStream_t stream) {
+    if (ls.total_items == 0) return hipSuccess;
     int nap = 1, grid = kStreamGrid;  // tuning knobs
     if (const char* v = std::getenv("LACX_PACK_NAP")) nap = std::atoi(v) > 0 ? std::atoi(v) : 1;
     if (const char* v = std::getenv("LACX_PACK_GRID")) grid = std::atoi(v) > 0 ? std::atoi(v) : grid;
-    hipLaunchKernelGGL(k_stream_out, dim3((uint32_t)grid), dim3(kStreamThreads), 0, stream, fuse_items, autost, nap, (const unsigned long long*)ws.size_rec,
-                       (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots, ws.slot_stride, out, out_cap,
-                       ws.packed, err_flag, err_flag + 1);
+    // counters: [0] error flags, [1] channel blocks put in place, [2] packer waves that gave up waiting
+    hipLaunchKernelGGL(k_stream_out, dim3((uint32_t)grid), dim3(kStreamThreads), 0, stream, ls.br, ls.total_items, nap, ls.item_stream,
+                       (const unsigned long long*)ws.size_rec, (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots,
+                       ws.slot_stride, out, ws.packed, counters, counters + 1, counters + 2);
     return hipGetLastError();
 }
 
-hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const AnalyzeParams& prm,
-                           const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev, const FuseArgs* fuse,
-                           hipEvent_t wait_before_full) {
+hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
+                           const FuseArgs* fuse, hipEvent_t wait_before_full) {
     const FuseArgs fa = fuse ? *fuse : FuseArgs{};
     hipError_t e = ensure_kernel_attrs();
     if (e != hipSuccess) return e;
-    const uint32_t nb = prm.num_blocks;
+    const BatchRef& br = ls.br;
+    const uint32_t nb = br.total_blocks;
     if (nb == 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], stream);
     e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, d_left, d_right, prm, ws.sums,
-                       ws.badidx, ws.acorr);
-    hipLaunchKernelGGL(k_stereo, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, ws.sums, ws.badidx, ws.bplans,
+    hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, br, ws.sums, ws.badidx, ws.acorr);
+    hipLaunchKernelGGL(k_stereo, dim3((nb + 3) / 4), dim3(64), 0, stream, br, ws.sums, ws.badidx, ws.bplans,
                        ws.need_probe, ws.need_full);
     hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
-                       sizeof(LevMem), stream, prm, ws.acorr, ws.need_probe, ws.lpcs);
+                       sizeof(LevMem), stream, br, ws.acorr, ws.need_probe, ws.lpcs);
     if (ev) (void)hipEventRecord(ev[1], stream);
-    const bool autost = prm.channels == 2 && prm.stereo_mode == 2;
-    if (autost) {
-        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, d_left,
-                           d_right, prm, 1, 0u, 0, ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr,
-                           (unsigned long long*)nullptr, FuseArgs{});
-        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, 1, ws.bplans, ws.need_probe,
+    // per-block stereo in any stream of the set: probes + decision; a final block of <= 4096 frames of such a stream can
+    // need all four channels (full LR-vs-MS comparison, ref lac/encoder.cpp:336-340)
+    bool any_auto = false, any_both = false;
+    uint32_t total_wg = 0;
+    for (uint32_t i = 0; i < ls.nstreams; ++i) {
+        const AnalyzeParams& p = ls.streams[i].prm;
+        const bool autost = p.channels == 2 && p.stereo_mode == 2;
+        any_auto = any_auto || autost;
+        any_both = any_both || (autost && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit);
+        total_wg += p.num_blocks * (p.channels == 2 ? 2u : 1u);
+    }
+    if (any_auto) {
+        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, br, 1, 0u, 0,
+                           ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
@@ -1843,20 +1980,21 @@ hipError_t launch_analysis(const int32_t* d_left, const int32_t* d_right, const 
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_full, 0);
         if (we != hipSuccess) return we;
     }
-    const uint32_t per = prm.channels == 2 ? 2u : 1u;
-    hipLaunchKernelGGL(k_analyze<GFull>, dim3(nb * per), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left,
-                       d_right, prm, 0, 0u, 0, ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa);
-    // Only a final block of <= 4096 frames can need all four channels (full LR-vs-MS comparison,
-    // ref lac/encoder.cpp:336-340): its 3rd and 4th slots go in a two-workgroup launch.
-    const uint64_t last_frames = prm.frames - (uint64_t)(nb - 1) * kMaxBlock;
-    if (autost && last_frames <= (uint64_t)kFullCompareLimit) {
-        hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, d_left, d_right,
-                           prm, 0, nb - 1, 2, ws.lpcs, ws.need_full, ws.plans, (unsigned long long*)nullptr,
-                           (unsigned long long*)nullptr, FuseArgs{});
+    hipLaunchKernelGGL(k_analyze<GFull>, dim3(total_wg), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
+                       ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa);
+    if (any_both) {  // the 3rd and 4th slots of such a final block: a two-workgroup launch each
+        for (uint32_t i = 0; i < ls.nstreams; ++i) {
+            const StreamDesc& sd = ls.streams[i];
+            const AnalyzeParams& p = sd.prm;
+            if (p.channels == 2 && p.stereo_mode == 2 && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit)
+                hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0,
+                                   sd.first_block + p.num_blocks - 1u, 2, ws.lpcs, ws.need_full, ws.plans,
+                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+        }
     }
     if (ev) (void)hipEventRecord(ev[3], stream);
-    if (autost && last_frames <= (uint64_t)kFullCompareLimit) {  // phase 2 only concerns such a final block
-        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, prm, 2, ws.bplans, ws.need_probe,
+    if (any_both) {  // phase 2 only concerns such final blocks
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 2, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[4], stream);

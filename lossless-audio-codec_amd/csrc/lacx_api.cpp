@@ -96,6 +96,10 @@ struct lacx_encoder {
     uint32_t h_table_blocks = 0;
     uint8_t* view_buf = nullptr;   // result of the host-emit fallback kept alive for the *_view API
     uint32_t* view_table = nullptr;
+    // lacx_encode_batch_device: the set's descriptors (host copy, device table + stream of every stream index)
+    std::vector<StreamDesc> batch_streams;
+    uint8_t* d_batch = nullptr;
+    size_t d_batch_cap = 0;
     std::unique_ptr<EmitPool> pool;
     std::string err;
     lacx_timing timing{};
@@ -175,7 +179,7 @@ int ensure_device(lacx_encoder* e) {
     for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipEventCreateWithFlags(&e->prologue, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
-    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 1), 0), "hipHostMalloc");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 4), 0), "hipHostMalloc");
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -207,6 +211,7 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.badidx) (void)hipFree(e->ws.badidx);
     if (e->ws.block_off) (void)hipFree(e->ws.block_off);
     if (e->ws.table) (void)hipFree(e->ws.table);
+    if (e->ws.stream_pre) (void)hipFree(e->ws.stream_pre);
     if (e->zero_region) (void)hipFree(e->zero_region);  // size_rec, ready_rec, tspan, emitted, packed, err_flag
     e->zero_region = nullptr;
     e->d_tspan = nullptr;
@@ -229,6 +234,7 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
                 "hipMalloc(block_off)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
+        HIP_TRY(e, hipMalloc((void**)&e->ws.stream_pre, ((size_t)nblocks + 1) * sizeof(unsigned long long)), "hipMalloc(stream prefixes)");
 
         // Everything a call needs zeroed up front lives in ONE allocation, cleared by one memset: the hand-off records
         // and flags of the fused emit (per channel block of the shard), the error flags, the kernel time stamps.
@@ -272,8 +278,8 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
 // and 5 any 24-bit material with room to spare (raw PCM is 2 resp. 3; the costliest constructible streams stay under
 // 1.2 x raw); a longer bitstream simply falls back to k_emit.  Device memory only: 48 KiB per channel block of 16-bit
 // audio (a 2 h stereo shard: 2 GB of the 288 GB).
-int ensure_slots(lacx_encoder* e, uint32_t nblocks, int channels) {
-    const unsigned long long stride = (unsigned long long)kMaxBlock * (e->cfg.bit_depth == 16 ? 3u : 5u);
+int ensure_slots(lacx_encoder* e, uint32_t nblocks, int channels, int bit_depth = 0) {
+    const unsigned long long stride = (unsigned long long)kMaxBlock * ((bit_depth ? bit_depth : e->cfg.bit_depth) == 16 ? 3u : 5u);
     const unsigned long long need = stride * nblocks * (unsigned)channels + 64u;
     if (need > e->slots_cap) {
         if (e->slots) (void)hipFree(e->slots);
@@ -331,6 +337,26 @@ AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, 
     const char* dbg = std::getenv("LACX_DEBUG_SKIP");  // timing ablations only
     prm.debug_skip = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
     return prm;
+}
+
+// Launch set of one stream (or one pipeline chunk of it): the descriptor travels in the kernel arguments.
+LaunchSet one_stream_set(const AnalyzeParams& prm, const int32_t* left, const int32_t* right, uint32_t fuse_items = 0,
+                         uint64_t out_cap = 0) {
+    StreamDesc sd{};
+    sd.prm = prm;
+    sd.left = left;
+    sd.right = right;
+    sd.first_block = 0;
+    sd.first_wg = 0;
+    sd.fuse_items = fuse_items;
+    sd.out_base = 0;
+    sd.out_cap = out_cap;
+    return single_set(sd);
+}
+// (LaunchSet::streams points into the set itself for one stream: fixed up wherever a set is copied or returned)
+const LaunchSet& bind(LaunchSet& ls) {
+    if (ls.br.table == nullptr) ls.streams = &ls.br.single;
+    return ls;
 }
 
 DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
@@ -434,7 +460,8 @@ int enqueue_chunk(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right
     const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
     const AnalyzeParams prm = make_params(e, f1 - f0, channels, stereo_mode, bit_depth);
     const DeviceWorkspace w = ws_at(e->ws, ck.first);
-    HIP_TRY(e, launch_analysis(d_left + f0, d_right ? d_right + f0 : nullptr, prm, w, st, e->ev[c]), "kernel launch");
+    LaunchSet ls = one_stream_set(prm, d_left + f0, d_right ? d_right + f0 : nullptr);
+    HIP_TRY(e, launch_analysis(bind(ls), w, st, e->ev[c]), "kernel launch");
     HIP_TRY(e, hipMemcpyAsync(e->h_plans + (size_t)ck.first * kSlotsPerBlock, w.plans,
                               (size_t)ck.count * kSlotsPerBlock * sizeof(ChannelPlan), hipMemcpyDeviceToHost, st),
             "D2H plans");
@@ -623,6 +650,13 @@ struct ChunkCtx {
     const int32_t* left;
     const int32_t* right;
     DeviceWorkspace w;
+    // the chunk as a launch set of one stream; fuse_items: its stream indices that take part in the fused emit,
+    // out_cap: capacity of the result buffer (offsets are shard-wide: out_base 0)
+    LaunchSet set(uint32_t shard_fuse_items, uint64_t out_cap) const {
+        const uint32_t items = prm.num_blocks * (uint32_t)prm.channels;
+        const uint32_t mine = shard_fuse_items > prm.stream_base ? std::min(items, shard_fuse_items - prm.stream_base) : 0u;
+        return one_stream_set(prm, left, right, mine, out_cap);
+    }
 };
 ChunkCtx chunk_ctx(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, int layout,
                    int channels, const Chunk& ck, size_t c) {
@@ -774,7 +808,6 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
             fa.err_flag = w.err_flag;
             fa.size_rec = e->ws.size_rec;
             fa.ready_rec = e->ws.ready_rec;
-            fa.fuse_items = fuse_items;
         }
         if (hs) {  // this chunk's PCM: host -> device, on the chunk's stream, right in front of its kernels
             const auto th0 = clk::now();
@@ -792,14 +825,21 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         // order too (chunk c's waits for chunk c-1's: ev[c-1][3] is recorded behind it); what comes before them --
         // ingest, Levinson, probes -- still overlaps the previous chunk's analysis.
         const bool chain = fused && c > 0 && !std::getenv("LACX_NO_CHAIN");
-        HIP_TRY(e, launch_analysis(cl, cr, prm, w, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
+        (void)cl;
+        (void)cr;
+        (void)prm;
+        LaunchSet ls = cx.set(fuse_items, emit_cap);
+        HIP_TRY(e, launch_analysis(bind(ls), w, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
         if (c == 0 && fuse_items && !std::getenv("LACX_NO_PACKER")) {
             // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first
             // chunk's ingest / Levinson / probe kernels are done (ev[0][2] is recorded right in front of the whole-block
             // kernel), so its bounded waits only ever cover the progress of the analysis itself, however long the shard.
             HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][2], 0), "stream wait");
-            HIP_TRY(e, launch_stream_out(fuse_items, (channels == 2 && e->cfg.stereo_mode == 2) ? 1 : 0, e->ws, emit_dst,
-                                         emit_cap, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
+            // (the packer walks the whole shard: one stream whose indices start at 0)
+            AnalyzeParams shard_prm = make_params(e, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
+            shard_prm.stream_base = 0;
+            LaunchSet shard = one_stream_set(shard_prm, nullptr, nullptr, fuse_items, emit_cap);
+            HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
         }
     }
@@ -815,9 +855,14 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         const DeviceWorkspace& w = cx.w;
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
         const bool packer_counts = fuse_items && !std::getenv("LACX_NO_PACKER");
-        HIP_TRY(e, launch_emit(cl, cr, prm, w, emit_dst, emit_cap, prev_end, c ? e->copied[c - 1] : nullptr,
+        (void)cl;
+        (void)cr;
+        (void)prm;
+        LaunchSet ls = cx.set(fuse_items, emit_cap);
+        HIP_TRY(e, launch_emit(bind(ls), w, emit_dst, prev_end, c ? e->copied[c - 1] : nullptr,
                                e->copied[c], s, true, packer_counts ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
-                               nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr), "emit launch");
+                               nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr,
+                               e->ws.err_flag + kMaxChunks + 3), "emit launch");
         prev_end = w.block_off + ck.count;
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
         // what the host reads afterwards, in one kernel that stores into the pinned buffers
@@ -835,7 +880,8 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         g.add(w.table, m_table + (size_t)ck.first * 2, (size_t)ck.count * 2 * sizeof(uint32_t));
         g.add(w.block_off + ck.count, &m_totals[c], sizeof(unsigned long long));
         g.add(w.err_flag, &m_err[c], sizeof(uint32_t));
-        if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], sizeof(uint32_t));
+        // the packer's error flags, moved count, waves that gave up, and k_pack's repacked count
+        if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
         if (fused)
             g.add(e->ws.packed + (size_t)ck.first * channels, m_emitted + (size_t)ck.first * channels,
                   (size_t)ck.count * channels * sizeof(uint32_t));
@@ -882,8 +928,8 @@ int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size) {
     for (size_t c = 0; c < chunks.size(); ++c) {
         const ChunkCtx cx = chunk_ctx(e, e->pend.d_left, e->pend.d_right, e->pend.frames, e->pend.layout,
                                       e->pend.channels, chunks[c], c);
-        HIP_TRY(e, launch_emit(cx.left, cx.right, cx.prm, cx.w, dst, cap, prev_end, nullptr, nullptr, s,
-                               /*skip_emitted=*/false), "emit relaunch");
+        LaunchSet ls = cx.set(0, cap);
+        HIP_TRY(e, launch_emit(bind(ls), cx.w, dst, prev_end, nullptr, nullptr, s, /*skip_emitted=*/false), "emit relaunch");
         prev_end = cx.w.block_off + chunks[c].count;
         HIP_TRY(e, hipMemcpyAsync(&e->h_err[c], cx.w.err_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "D2H err");
     }
@@ -975,9 +1021,11 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     }
     e->timing.full_launches = (uint32_t)chunks.size();
     e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
-    e->timing.emit_direct = e->timing.emit_parked = 0;
+    e->timing.emit_direct = e->timing.moved_by_k_pack = e->timing.packer_gave_up = 0;
     if (e->pend.fused) {
         for (size_t i = 0; i < (size_t)nb * (size_t)channels; ++i) e->timing.emit_direct += e->h_emitted[i] == 1u;
+        e->timing.packer_gave_up = e->h_err[kMaxChunks + 2];
+        e->timing.moved_by_k_pack = e->h_err[kMaxChunks + 3];
     }
     e->timing.full_exec_ms = 0;
     for (size_t c = 0; c < chunks.size(); ++c) {
@@ -1031,6 +1079,222 @@ int prepare(lacx_encoder* e, const void* left, uint64_t frames) {
     rc = ensure_device(e);
     if (rc) return rc;
     HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    return LACX_OK;
+}
+
+// ---- many streams as ONE launch set (lacx_encode_batch_device) ------------------------------------------------------
+// Every stream keeps its own parameters (rate, depth, channels, stereo mode, layout); the kernels resolve the stream of a
+// block from the descriptor table (StreamDesc, lacx_types.h).  One ingest / Levinson / probe / whole-block launch over
+// all blocks of all streams, one packer; every stream's payload lands in its own region of the pinned result buffer.
+int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipStream_t user_stream, lacx_batch_out* out) {
+    if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
+    std::vector<StreamDesc>& sds = e->batch_streams;
+    sds.assign(n, StreamDesc{});
+    uint32_t nb = 0, nitems = 0, nwg = 0;
+    uint64_t region = 0;
+    int max_depth = 16;
+    for (uint32_t i = 0; i < n; ++i) {
+        const lacx_batch_item& it = items[i];
+        const std::string who = "stream " + std::to_string(i) + ": ";
+        if (it.pcm.data0 == nullptr || it.frames == 0) return fail(e, LACX_E_INVALID, who + "left channel must not be empty");
+        if (!rate_ok(it.sample_rate)) return fail(e, LACX_E_INVALID, who + "unsupported sample rate: " + std::to_string(it.sample_rate));
+        if (!(it.bit_depth == 16 || it.bit_depth == 24)) return fail(e, LACX_E_INVALID, who + "unsupported bit depth: " + std::to_string((int)it.bit_depth));
+        if (it.stereo_mode > 2) return fail(e, LACX_E_INVALID, who + "unsupported stereo mode: " + std::to_string((int)it.stereo_mode));
+        if (it.pcm.channels != 1 && it.pcm.channels != 2) return fail(e, LACX_E_INVALID, who + "unsupported channel count");
+        int layout = 0;
+        if (it.pcm.layout == LACX_PCM_PLANAR_I32) {
+            if ((it.pcm.channels == 2) != (it.pcm.data1 != nullptr))
+                return fail(e, LACX_E_INVALID, who + "planar PCM: data1 must be the right channel of stereo input and null for mono");
+        } else if (it.pcm.layout == LACX_PCM_INTERLEAVED_I16 || it.pcm.layout == LACX_PCM_INTERLEAVED_I24) {
+            if ((it.pcm.layout == LACX_PCM_INTERLEAVED_I16 ? 16 : 24) != it.bit_depth)
+                return fail(e, LACX_E_INVALID, who + "PCM layout does not match the bit depth");
+            layout = (int)it.pcm.layout;
+        } else {
+            return fail(e, LACX_E_INVALID, who + "unknown PCM layout");
+        }
+        const int channels = (int)it.pcm.channels;
+        StreamDesc& sd = sds[i];
+        sd.prm = make_params(e, it.frames, channels, it.stereo_mode, it.bit_depth, layout);
+        sd.prm.stream_base = nitems;
+        sd.left = static_cast<const int32_t*>(it.pcm.data0);
+        sd.right = layout ? nullptr : static_cast<const int32_t*>(it.pcm.data1);
+        sd.first_block = nb;
+        sd.first_wg = nwg;
+        sd.pad = i;  // the stream's number in the table (k_offsets)
+        const uint32_t snb = sd.prm.num_blocks;
+        const uint64_t last_frames = it.frames - (uint64_t)(snb - 1) * kMaxBlock;
+        const bool last_both_ways = channels == 2 && it.stereo_mode == 2 && last_frames <= (uint64_t)kFullCompareLimit;
+        sd.fuse_items = (snb - (last_both_ways ? 1u : 0u)) * (uint32_t)channels;
+        sd.out_base = region;
+        sd.out_cap = it.frames * (uint64_t)channels * (it.bit_depth / 8u) * 5u / 4u + (uint64_t)snb * 64u + 4096u;
+        region += (sd.out_cap + 4095u) & ~4095ull;
+        if ((uint64_t)nb + snb > 0x7FFFFFFFull / kSlotsPerBlock) return fail(e, LACX_E_INVALID, "too many blocks in one batch");
+        nb += snb;
+        nitems += snb * (uint32_t)channels;
+        nwg += snb * (uint32_t)channels;
+        max_depth = std::max(max_depth, (int)it.bit_depth);
+    }
+    if (n > 65535u) return fail(e, LACX_E_INVALID, "more than 65535 streams in one batch");
+    int rc = ensure_workspace(e, nb);
+    if (rc) return rc;
+    // staging slots: one stride for the whole set (the deepest material's)
+    {
+        const int save = e->cfg.bit_depth;
+        (void)save;
+        rc = ensure_slots(e, nitems, 1, max_depth);
+        if (rc) return rc;
+    }
+    if (region > e->h_payload_cap) {
+        if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
+        e->h_payload = e->h_payload_base = nullptr;
+        e->h_payload_cap = e->h_prefix = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_payload_base, region, 0), "hipHostMalloc(payload)");
+        e->h_payload = e->h_payload_base;
+        e->h_payload_cap = region;
+    }
+    if (nb > e->h_table_blocks) {
+        if (e->h_table) (void)hipHostFree(e->h_table);
+        e->h_table = nullptr;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_table, (size_t)nb * 2 * sizeof(uint32_t), 0), "hipHostMalloc(table)");
+        e->h_table_blocks = nb;
+    }
+    if (nb * 2u > e->h_emitted_cap) {
+        if (e->h_emitted) (void)hipHostFree(e->h_emitted);
+        e->h_emitted = nullptr;
+        e->h_emitted_cap = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_emitted, (size_t)nb * 2 * sizeof(uint32_t), 0), "hipHostMalloc(emitted)");
+        e->h_emitted_cap = nb * 2u;
+    }
+    // descriptor table + the stream of every stream index -> device
+    const size_t tab_bytes = ((size_t)n * sizeof(StreamDesc) + 15) & ~(size_t)15, map_bytes = (size_t)nitems * sizeof(uint16_t);
+    if (tab_bytes + map_bytes > e->d_batch_cap) {
+        if (e->d_batch) (void)hipFree(e->d_batch);
+        e->d_batch = nullptr;
+        e->d_batch_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_batch, tab_bytes + map_bytes), "hipMalloc(batch table)");
+        e->d_batch_cap = tab_bytes + map_bytes;
+    }
+    std::vector<uint16_t> item_stream(nitems);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t cnt = sds[i].prm.num_blocks * (uint32_t)sds[i].prm.channels;
+        std::fill(item_stream.begin() + sds[i].prm.stream_base, item_stream.begin() + sds[i].prm.stream_base + cnt, (uint16_t)i);
+    }
+    reset_device_timing(e);
+    e->timing.emit_ms = 0;
+    const auto t0 = clk::now();
+    hipStream_t s = user_stream ? user_stream : e->stream[0];
+    HIP_TRY(e, hipMemcpyAsync(e->d_batch, sds.data(), (size_t)n * sizeof(StreamDesc), hipMemcpyHostToDevice, s), "H2D batch table");
+    HIP_TRY(e, hipMemcpyAsync(e->d_batch + tab_bytes, item_stream.data(), map_bytes, hipMemcpyHostToDevice, s), "H2D batch map");
+    HIP_TRY(e, hipStreamSynchronize(s), "synchronize");  // (item_stream is a local; the copies are tiny)
+    LaunchSet ls;
+    ls.br.table = reinterpret_cast<const StreamDesc*>(e->d_batch);
+    ls.br.nstreams = n;
+    ls.br.total_blocks = nb;
+    ls.br.single = StreamDesc{};
+    ls.streams = sds.data();
+    ls.nstreams = n;
+    ls.total_items = nitems;
+    ls.item_stream = reinterpret_cast<const uint16_t*>(e->d_batch + tab_bytes);
+    uint8_t* emit_dst = nullptr;
+    HIP_TRY(e, hipHostGetDevicePointer((void**)&emit_dst, e->h_payload, 0), "hipHostGetDevicePointer");
+    HIP_TRY(e, hipMemsetAsync(e->zero_region, 0, e->zero_bytes, s), "memset");
+    DeviceWorkspace w = e->ws;
+    w.t_first = e->d_tspan;
+    w.t_last = e->d_tspan + kMaxChunks;
+    FuseArgs fa;
+    fa.slots = e->ws.slots;
+    fa.slot_stride = e->ws.slot_stride;
+    fa.emitted = e->ws.emitted;
+    fa.err_flag = w.err_flag;
+    fa.size_rec = e->ws.size_rec;
+    fa.ready_rec = e->ws.ready_rec;
+    auto run = [&]() -> int {
+        HIP_TRY(e, launch_analysis(ls, w, s, e->ev[0], &fa, nullptr), "kernel launch");
+        const bool packer = !std::getenv("LACX_NO_PACKER");
+        if (packer) {
+            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][2], 0), "stream wait");
+            HIP_TRY(e, launch_stream_out(ls, e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
+            HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
+        }
+        HIP_TRY(e, launch_emit(ls, w, emit_dst, nullptr, nullptr, nullptr, s, true, packer ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
+                               nitems, packer ? e->pack_done : nullptr, e->ws.err_flag + kMaxChunks + 3), "emit launch");
+        HIP_TRY(e, hipEventRecord(e->ev[0][5], s), "event record");
+        GatherList g;
+        auto mapped = [](auto* host) -> decltype(host) {
+            void* d = nullptr;
+            return hipHostGetDevicePointer(&d, host, 0) == hipSuccess ? static_cast<decltype(host)>(d) : nullptr;
+        };
+        BlockPlan* m_bplans = mapped(e->h_bplans);
+        uint32_t *m_table = mapped(e->h_table), *m_err = mapped(e->h_err), *m_emitted = mapped(e->h_emitted);
+        unsigned long long* m_tspan = mapped(e->h_tspan);
+        if (!m_bplans || !m_table || !m_err || !m_tspan || !m_emitted) return fail(e, LACX_E_RUNTIME, "hipHostGetDevicePointer failed");
+        g.add(w.bplans, m_bplans, (size_t)nb * sizeof(BlockPlan));
+        g.add(w.table, m_table, (size_t)nb * 2 * sizeof(uint32_t));
+        g.add(w.err_flag, &m_err[0], sizeof(uint32_t));
+        g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
+        g.add(e->ws.packed, m_emitted, (size_t)nitems * sizeof(uint32_t));
+        g.add(w.t_first, &m_tspan[0], sizeof(unsigned long long));
+        g.add(w.t_last, &m_tspan[kMaxChunks], sizeof(unsigned long long));
+        HIP_TRY(e, launch_gather(g, s), "gather launch");
+        HIP_TRY(e, hipEventRecord(e->done[0], s), "event record");
+        HIP_TRY(e, hipEventSynchronize(e->done[0]), "event synchronize");
+        return LACX_OK;
+    };
+    rc = run();
+    if (rc != LACX_OK) {
+        (void)hipDeviceSynchronize();
+        return rc;
+    }
+    e->timing.d2h_ms = ms_since(t0);
+    for (uint32_t i = 0; i < n; ++i) {  // sample-range errors, stream by stream, the reference's wording per stream
+        const StreamDesc& sd = sds[i];
+        for (int pass = 0; pass < 2; ++pass) {
+            for (uint32_t b = 0; b < sd.prm.num_blocks; ++b) {
+                const BlockPlan& bp = e->h_bplans[sd.first_block + b];
+                if (!bp.invalid) continue;
+                const bool is_right = (bp.first_bad >> 31) != 0;
+                if ((pass == 0) == is_right) continue;
+                const uint64_t idx = (uint64_t)b * kMaxBlock + (bp.first_bad & 0x7FFFFFFFu);
+                return fail(e, LACX_E_INVALID, "stream " + std::to_string(i) + ": " + (is_right ? "right" : "left") +
+                                                   " sample at index " + std::to_string(idx) + " is outside the configured PCM bit depth");
+            }
+        }
+    }
+    if (e->h_err[0] & 1u) return fail(e, LACX_E_RUNTIME, "device emit disagrees with the analysis plan (internal error)");
+    if ((e->h_err[0] & 2u) || (e->h_err[kMaxChunks] & 2u))
+        return fail(e, LACX_E_RUNTIME, "a stream's payload exceeds its pinned result reservation");
+    add_chunk_timing(e, 0);
+    {
+        float f = 0;
+        if (hipEventElapsedTime(&f, e->ev[0][4], e->ev[0][5]) == hipSuccess) e->timing.emit_ms += f;
+        (void)hipGetLastError();
+    }
+    e->timing.full_launches = 1;
+    e->timing.full_slots = nitems;
+    e->timing.emit_direct = 0;
+    for (uint32_t i = 0; i < nitems; ++i) e->timing.emit_direct += e->h_emitted[i] == 1u;
+    e->timing.packer_gave_up = e->h_err[kMaxChunks + 2];
+    e->timing.moved_by_k_pack = e->h_err[kMaxChunks + 3];
+    {
+        const unsigned long long a = ~e->h_tspan[0], b = e->h_tspan[kMaxChunks];
+        e->timing.full_exec_ms = b > a ? (double)(b - a) * 1e-5 : 0.0;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const StreamDesc& sd = sds[i];
+        uint64_t bytes = 0;
+        for (uint32_t b = 0; b < sd.prm.num_blocks; ++b) {
+            const uint32_t by = e->h_table[2 * ((size_t)sd.first_block + b) + 1];
+            if (by == 0) return fail(e, LACX_E_RUNTIME, "encoded block size is outside format limits");
+            bytes += by;
+        }
+        if (bytes > sd.out_cap) return fail(e, LACX_E_RUNTIME, "a stream's payload exceeds its pinned result reservation");
+        out[i].payload = e->h_payload + sd.out_base;
+        out[i].payload_size = bytes;
+        out[i].table = e->h_table + 2 * (size_t)sd.first_block;
+        out[i].nblocks = sd.prm.num_blocks;
+        out[i].reserved = 0;
+    }
+    e->timing.total_ms = ms_since(t0);
     return LACX_OK;
 }
 
@@ -1089,6 +1353,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->d_payload) (void)hipFree(e->d_payload);
         if (e->slots) (void)hipFree(e->slots);
         if (e->d_raw) (void)hipFree(e->d_raw);
+        if (e->d_batch) (void)hipFree(e->d_batch);
         if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -1403,6 +1668,17 @@ int lacx_encode_shard_pcm_device_view(lacx_encoder* e, const lacx_pcm* pcm, uint
     const int rc = lacx_encode_shard_pcm_device_begin(e, pcm, frames, stream);
     if (rc) return rc;
     return lacx_encode_shard_end(e, payload, payload_size, table, nblocks);
+}
+
+int lacx_encode_batch_device(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, void* stream, lacx_batch_out* out) {
+    if (!e || !items || !out || n == 0) return LACX_E_INVALID;
+    e->timing = lacx_timing{};
+    if (e->cfg.flags & LACX_FLAG_HOST_EMIT)
+        return fail(e, LACX_E_INVALID, "this entry point needs the device-side emit (LACX_FLAG_HOST_EMIT is set)");
+    int rc = ensure_device(e);
+    if (rc) return rc;
+    HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
+    return encode_batch(e, items, n, static_cast<hipStream_t>(stream), out);
 }
 
 int lacx_encode_shard_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right,

@@ -64,4 +64,30 @@ struct AnalyzeParams {
     uint32_t stream_base;  // fused emit: stream index (block * channels + channel) of the chunk's first channel block
 };
 
+// One input stream of a launch set.  A launch set covers the blocks of one or many streams (lacx_encode_batch: the files
+// of a corpus as ONE job, ref src/codec/lac/encoder.cpp:404-435 keeps one pool over all blocks): global block g of the
+// set belongs to the stream with first_block <= g < first_block + prm.num_blocks and is block g - first_block of it.
+// Workspace arrays (plans, need masks, autocorrelations ...) are indexed by the global block, sample addresses and block
+// geometry by the stream's own block number.
+struct StreamDesc {
+    AnalyzeParams prm;              // the stream's parameters; prm.stream_base = its first stream index (block * channels + channel, over the set)
+    const int32_t* left;            // planar: left channel; interleaved layouts: the WAV data chunk
+    const int32_t* right;           // planar: right channel (null for mono)
+    uint32_t first_block;           // first global block
+    uint32_t first_wg;              // first workgroup in the grid of the whole-block analysis kernel (channels per block)
+    uint32_t fuse_items;            // stream indices [prm.stream_base, prm.stream_base + fuse_items) take part in the fused emit
+    uint32_t pad;                   // the stream's number in a table of several
+    unsigned long long out_base;    // byte offset of the stream's payload region in the result buffer
+    unsigned long long out_cap;     // bytes reserved for it
+};
+
+// What every kernel gets: a table of streams in device memory, or -- one stream, the common case -- the descriptor
+// itself in the kernel arguments (table == nullptr; no upload, no look-up).
+struct BatchRef {
+    const StreamDesc* table;
+    uint32_t nstreams;
+    uint32_t total_blocks;
+    StreamDesc single;
+};
+
 }  // namespace lacx

@@ -79,7 +79,9 @@ class Timing(C.Structure):
         ("regrows", C.c_uint32),
         ("full_exec_ms", C.c_double),
         ("emit_direct", C.c_uint32),
-        ("emit_parked", C.c_uint32),
+        ("moved_by_k_pack", C.c_uint32),
+        ("packer_gave_up", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 
@@ -89,7 +91,7 @@ EXPORTS = (
     "lacx_encode_shard", "lacx_encode_shard_device", "lacx_encode_shard_device_view", "lacx_encode_shard_pcm_device_view", "lacx_assemble", "lacx_block_encode",
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
     "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers", "lacx_encode_wav_view",
-    "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error",
+    "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error", "lacx_encode_batch_device",
 )
 
 
@@ -567,3 +569,48 @@ class BlockEncoder:
         if rc != OK:
             _raise(h, rc)
         return ac, coef, used
+
+
+class BatchItem(C.Structure):
+    _fields_ = [("pcm", Pcm), ("frames", C.c_uint64), ("sample_rate", C.c_uint32), ("bit_depth", C.c_uint8),
+                ("stereo_mode", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("payload", C.POINTER(C.c_uint8)), ("payload_size", C.c_uint64), ("table", C.POINTER(C.c_uint32)),
+                ("nblocks", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BatchEncoder:
+    """Many streams as ONE device job (lacx_encode_batch_device): every stream keeps its own rate, depth, channels and
+    stereo mode.  formats: [(sample_rate, bit_depth, stereo_mode), ...] in the order the streams are passed later."""
+
+    def __init__(self, formats, device: int = -1, zero_run: bool = True, partitioning: bool = True):
+        self.formats = [tuple(f) for f in formats]
+        self._enc = Encoder(12, 2, 48000, 16, device=device)
+        self._enc.set_zero_run_enabled(zero_run)
+        self._enc.set_partitioning_enabled(partitioning)
+
+    def timing(self) -> Timing:
+        return self._enc.timing()
+
+    def encode_device(self, streams, stream: int = 0):
+        """streams: [(data_ptr, layout, channels, frames[, data1_ptr]), ...] device-resident PCM; returns a list of
+        (PayloadView, table uint32[nblocks, 2]) views into the encoder's pinned result buffer."""
+        n = len(streams)
+        if n != len(self.formats):
+            raise ValueError("one stream per format")
+        items = (BatchItem * n)()
+        for it, st, (sr, bd, sm) in zip(items, streams, self.formats):
+            ptr, layout, ch, frames = st[:4]
+            it.pcm = Pcm(ptr, st[4] if len(st) > 4 else None, layout, ch)
+            it.frames = frames
+            it.sample_rate = sr
+            it.bit_depth = bd
+            it.stereo_mode = sm
+        outs = (BatchOut * n)()
+        h = self._enc._handle()
+        rc = lib().lacx_encode_batch_device(h, items, C.c_uint32(n), C.c_void_p(stream), outs)
+        if rc != OK:
+            _raise(h, rc)
+        return [(PayloadView(o.payload, o.payload_size), np.ctypeslib.as_array(o.table, shape=(o.nblocks, 2))) for o in outs]

@@ -10,6 +10,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, liblacx.so links the system one.  Loaded
+    # torch-first the two share a runtime; the other way round torch later finds "No HIP GPUs".  Some GPU tests hand
+    # torch tensors to the library, so torch goes first whatever subset of the tests is selected.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

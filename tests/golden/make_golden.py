@@ -58,20 +58,21 @@ DIGESTS = [
     ("cfg4_2h_shard8of8_st16_48k", 345_600_000 - 18457 * 16384, 2, 16, 48000, 2, "music", "wide", 2026, False, True,
      18457 * 16384),
 ]
-# BASELINE configs[2] at its stated size (10 min stereo 24-bit 96 kHz, 57.6 M frames, 3516 blocks), one minute of white
+# BASELINE configs[2] at its stated size (10 min stereo 24-bit 96 kHz, 57.6 M frames, 3516 blocks), one and ten minutes of white
 # noise (every block "uncertain": all twelve probes, about five exactly costed candidates per slot), and the sixteen
 # streams of BASELINE configs[4] ({mono, stereo} x {16, 24 bit} x {44.1, 48, 96, 192 kHz}, 60 s each; stream i: seed
 # 500 + i, "mixed" material for odd i, "music" for even i): bench.py times them after the headline loop and checks every
 # .lac against these digests ("other_workloads").
 DIGESTS.append(("cfg3_10min_st24_96k_mixed", 57_600_000, 2, 24, 96000, 2, "mixed", "wide", 7, False, True))
 DIGESTS.append(("noise_60s_st16_48k", 2_880_000, 2, 16, 48000, 2, "noise", "independent", 3, False, True))
+DIGESTS.append(("noise_10min_st16_48k", 28_800_000, 2, 16, 48000, 2, "noise", "independent", 3, False, False))
 CFG5 = []
 for _ch in (1, 2):
     for _bd in (16, 24):
         for _sr in (44100, 48000, 96000, 192000):
             _i = len(CFG5)
             CFG5.append((f"cfg5_{_i:02d}_{'st' if _ch == 2 else 'mono'}{_bd}_{_sr}", 60 * _sr, _ch, _bd, _sr, 2 if _ch == 2 else 0,
-                         "mixed" if _i & 1 else "music", "wide", 500 + _i, False, _i in (0, 7, 10, 15)))
+                         "mixed" if _i & 1 else "music", "wide", 500 + _i, False, True))
 DIGESTS.extend(CFG5)
 # The other seven eighths of the same 2 h stream (block ranges [r*B/8, (r+1)*B/8), B = 21 094): bench.py --gpus 2/4/8
 # has every rank check each eighth of its shard against these (the N = 2 and N = 4 boundaries are N = 8 boundaries).

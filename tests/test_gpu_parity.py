@@ -175,7 +175,7 @@ def test_golden_digests(gpu):
     with open(path) as f:
         entries = json.load(f)
     for ent in entries:
-        if ent.get("gpu_test", True) is False:
+        if ent.get("gpu_test", True) is False or ent["name"].startswith("cfg5_"):
             continue
         g = ent["gen"]
         left, right = gpu.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"],
@@ -187,6 +187,31 @@ def test_golden_digests(gpu):
             got = enc.encode(left, right)
             assert len(got) == ent["lac_bytes"], (ent["name"], host_emit)
             assert hashlib.sha256(got).hexdigest() == ent["lac_sha256"], (ent["name"], host_emit)
+
+
+def test_golden_digests_of_the_mixed_corpus_as_one_batch(gpu):
+    """BASELINE configs[4]: the reference-minted cfg5_* digests, their streams encoded as ONE batch job."""
+    import torch
+
+    with open(os.path.join(GOLDEN, "digests.json")) as f:
+        entries = [e for e in json.load(f) if e["name"].startswith("cfg5_") and e.get("gpu_test", True)]
+    assert entries
+    streams, keep = [], []
+    for ent in entries:
+        g = ent["gen"]
+        left, right = gpu.synth.synth_pcm(g["frames"], g["channels"], g["bit_depth"], g["sample_rate"], seed=g["seed"],
+                                          kind=g["kind"], stereo=g.get("stereo", "wide"))
+        inter = gpu.synth.interleave(left, right, g["bit_depth"])
+        d = torch.from_numpy(inter.view(np.int16) if g["bit_depth"] == 16 else inter).cuda()
+        keep.append(d)
+        streams.append((d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16 if g["bit_depth"] == 16 else gpu.lacx.PCM_INTERLEAVED_I24,
+                        g["channels"], g["frames"]))
+    be = gpu.lacx.BatchEncoder([(e["gen"]["sample_rate"], e["gen"]["bit_depth"], e["stereo_mode"]) for e in entries], device=0)
+    res = be.encode_device(streams)
+    for ent, (pay, tab) in zip(entries, res):
+        g = ent["gen"]
+        got = gpu.lacx.assemble(g["sample_rate"], g["bit_depth"], ent["stereo_mode"], g["channels"], [(pay.tobytes(), tab.copy())])
+        assert len(got) == ent["lac_bytes"] and hashlib.sha256(got).hexdigest() == ent["lac_sha256"], ent["name"]
 
 
 def test_cpp_mirror_classes_on_device(gpu):
@@ -560,3 +585,48 @@ def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
             t = enc.timing()
             small_last = ch == 2 and sm == 2 and (frames % 16384) and (frames % 16384) <= 4096
             assert t.emit_direct == (-(-frames // 16384) - (1 if small_last else 0)) * ch
+
+
+def test_batch_of_streams_is_one_job_with_the_same_bytes(gpu, oracle):
+    """lacx_encode_batch_device: streams of different rate / depth / channels / stereo mode as ONE launch set (BASELINE
+    configs[4]).  Every stream's (payload, table) must assemble to the bytes the oracle gives for that stream alone --
+    including streams of one block, ragged final blocks, a final block of <= 4096 frames that is encoded both ways and
+    compared (left to the repair emit), forced LR / MS, and mono."""
+    import torch
+
+    specs = [
+        # frames, channels, bit_depth, rate, stereo_mode, kind
+        (16384 * 3 + 500, 2, 16, 48000, 2, "mixed"),
+        (16384 * 2 + 77, 1, 16, 44100, 0, "music"),
+        (16384 * 2 + 4001, 2, 24, 96000, 2, "mixed"),     # final block <= 4096 frames: both ways
+        (5000, 1, 24, 48000, 0, "noise"),
+        (16384 * 2, 2, 16, 48000, 1, "music"),
+        (300, 2, 16, 192000, 2, "noise"),                  # one small block, both ways
+        (16384 * 4 + 12000, 2, 24, 192000, 0, "music"),
+        (16384, 2, 16, 96000, 2, "silence"),
+        (16384 * 2 + 9, 2, 16, 44100, 2, "near_silence"),
+    ]
+    streams, keep, want = [], [], []
+    for i, (frames, ch, bd, sr, sm, kind) in enumerate(specs):
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=40 + i, kind=kind)
+        inter = gpu.synth.interleave(left, right, bd)
+        d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+        keep.append(d)
+        streams.append((d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24, ch, frames))
+        want.append(oracle.encode(left, right, sr, bd, sm if ch == 2 else 0, threads=8))
+    be = gpu.lacx.BatchEncoder([(sr, bd, sm if ch == 2 else 0) for (_, ch, bd, sr, sm, _) in specs], device=0)
+    for rep in range(2):  # the second call reuses every buffer
+        res = be.encode_device(streams, torch.cuda.current_stream().cuda_stream)
+        for (frames, ch, bd, sr, sm, _), (pay, tab), w in zip(specs, res, want):
+            got = gpu.lacx.assemble(sr, bd, sm if ch == 2 else 0, ch, [(pay.tobytes(), tab.copy())])
+            assert got == w, (frames, ch, bd, sr, sm, rep)
+    t = be.timing()
+    assert t.packer_gave_up == 0
+    # a sample outside the bit depth names its stream (planar int32 input can hold one)
+    bad_l, bad_r = gpu.synth.synth_pcm(20000, 2, 16, 48000, seed=3, kind="music")
+    bad_l = bad_l.copy()
+    bad_l[17000] = 40000
+    dl, dr = torch.from_numpy(bad_l).cuda(), torch.from_numpy(bad_r).cuda()
+    be2 = gpu.lacx.BatchEncoder([(sr, bd, sm if ch == 2 else 0) for (_, ch, bd, sr, sm, _) in specs[:1]] + [(48000, 16, 2)], device=0)
+    with pytest.raises(ValueError, match=r"stream 1: left sample at index 17000 is outside"):
+        be2.encode_device(streams[:1] + [(dl.data_ptr(), gpu.lacx.PCM_PLANAR_I32, 2, 20000, dr.data_ptr())])
