@@ -257,7 +257,10 @@ int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, in
                 float* device_ms);
 const char* lacx_decode_last_error(void); /* of the calling thread */
 
-/* Block::Encoder::encode drop-in for one channel block of n <= 16384 samples, |x| <= 2^24. */
+/* Block::Encoder::encode drop-in for one channel block of n <= 16384 samples of ANY int32 value: blocks inside the 25-bit
+ * mid/side domain of validated 16 / 24-bit input run on the streaming kernels, wider ones on a kernel of their own that
+ * follows the reference through its int32-overflow order fallback (ref lpc.cpp:24-36, 188-229) and up to k = 31.
+ * More than 16384 samples: LACX_E_INVALID (the LAC container cannot carry such a block). */
 int lacx_block_encode(lacx_encoder* enc, const int32_t* pcm, uint32_t n, uint8_t** out, uint64_t* out_size);
 int lacx_block_plan_only(lacx_encoder* enc, const int32_t* pcm, uint32_t n, lacx_channel_plan* plan);
 

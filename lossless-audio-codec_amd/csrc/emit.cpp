@@ -39,7 +39,7 @@ public:
     // Rice code of u with parameter k: q ones, a zero, k remainder bits (ref rice.cpp:17-32).
     inline void rice(uint32_t u, uint32_t k) {
         const uint32_t q = (k >= 32u) ? 0u : (u >> k);
-        if (q + 1u + k <= 32u) {
+        if (q < 32u && q + 1u + k <= 32u) {  // (q itself can be anything up to 2^32 - 1 outside the validated domain)
             const uint32_t rem = k ? (u & ((1u << k) - 1u)) : 0u;
             const uint32_t un = (q ? (((1u << q) - 1u) << 1) : 0u);  // q ones then a zero
             put(k ? ((un << k) | rem) : un, q + 1u + k);
@@ -97,7 +97,8 @@ public:
         if (c > 256u) wsum_ -= ring_[slot];
         ring_[slot] = u;
         wsum_ += u;
-        const uint32_t km = kmean(sum_, c);
+        uint32_t km = kmean(sum_, c);
+        if (km > 31u) km = 31u;  // ref rice.hpp:68-71 (only a mean of 2^31 and more gets here: Block::Encoder's wide domain)
         const uint32_t q = (km >= 31u) ? 0u : (u >> km);
         const uint32_t mslot = (c - 1u) % 96u;
         large_ += (q > 3u) - fl_[mslot];
@@ -140,11 +141,13 @@ struct MeanModel {  // adapt_k_stateless
     inline uint32_t push(uint32_t u) {
         sum += u;
         ++count;
-        return kmean(sum, count);
+        const uint32_t k = kmean(sum, count);
+        return k > 31u ? 31u : k;  // ref block/encoder.cpp:72-77
     }
     inline uint32_t skip(uint32_t run) {
         count += run;
-        return kmean(sum, count);
+        const uint32_t k = kmean(sum, count);
+        return k > 31u ? 31u : k;
     }
 };
 

@@ -124,6 +124,11 @@ hipError_t launch_decode_serial(uint32_t num_blocks, int channels, int stereo_mo
                                 uint32_t payload_bits, const unsigned long long* frame_off, int32_t* left, int32_t* right,
                                 uint32_t* status, uint8_t* ms_flag, hipStream_t stream);
 
+// Block::Encoder::encode's analysis for one block of arbitrary int32 samples (wide.hip): d_res = scratch for the eleven
+// candidate residuals ([11][kMaxBlock] int32), d_plan receives the plan.
+hipError_t launch_wide_block(const int32_t* d_x, uint32_t n, int zero_run, int partitioning, int32_t* d_res,
+                             ChannelPlan* d_plan, hipStream_t stream);
+
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.
 int debug_read_stamps(unsigned long long* out32);

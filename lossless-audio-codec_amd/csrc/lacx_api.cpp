@@ -100,6 +100,7 @@ struct lacx_encoder {
     std::vector<StreamDesc> batch_streams;
     uint8_t* d_batch = nullptr;
     size_t d_batch_cap = 0;
+    int32_t* d_wide = nullptr;  // lacx_block_encode outside the 25-bit domain: the eleven candidate residuals (wide.hip)
     std::unique_ptr<EmitPool> pool;
     std::string err;
     lacx_timing timing{};
@@ -1169,6 +1170,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     const size_t tab_bytes = ((size_t)n * sizeof(StreamDesc) + 15) & ~(size_t)15, map_bytes = (size_t)nitems * sizeof(uint16_t);
     if (tab_bytes + map_bytes > e->d_batch_cap) {
         if (e->d_batch) (void)hipFree(e->d_batch);
+        if (e->d_wide) (void)hipFree(e->d_wide);
         e->d_batch = nullptr;
         e->d_batch_cap = 0;
         HIP_TRY(e, hipMalloc((void**)&e->d_batch, tab_bytes + map_bytes), "hipMalloc(batch table)");
@@ -1354,6 +1356,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->slots) (void)hipFree(e->slots);
         if (e->d_raw) (void)hipFree(e->d_raw);
         if (e->d_batch) (void)hipFree(e->d_batch);
+        if (e->d_wide) (void)hipFree(e->d_wide);
         if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
         if (e->h_table) (void)hipHostFree(e->h_table);
         if (e->h_totals) (void)hipHostFree(e->h_totals);
@@ -1984,13 +1987,19 @@ int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const 
     return LACX_OK;
 }
 
-static int block_domain_check(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
-    if (n > (uint32_t)kMaxBlock) return fail(e, LACX_E_INVALID, "block larger than 16384 samples");
-    for (uint32_t i = 0; i < n; ++i) {
-        if (pcm[i] > (1 << 24) || pcm[i] < -(1 << 24))
-            return fail(e, LACX_E_INVALID, "block sample outside the supported 25-bit mid/side domain");
-    }
+// Block::Encoder::encode takes any int32 samples (ref src/codec/block/encoder.cpp:313-316).  Blocks inside the 25-bit
+// mid/side domain of validated 16 / 24-bit input go through the streaming kernels; anything wider goes through the wide
+// kernel (wide.hip: residuals that leave int32 and the reference's order fallback, 32-bit zigzag values, k up to 31).
+// What stays out: blocks of more than 16384 samples -- the container cannot carry them (ref src/codec/lac/decoder.cpp
+// refuses a block size above Block::MAX_BLOCK_SIZE) and the kernels' images are sized for that maximum.
+static int block_size_check(lacx_encoder* e, uint32_t n) {
+    if (n > (uint32_t)kMaxBlock) return fail(e, LACX_E_INVALID, "block larger than 16384 samples (the LAC container cannot carry it)");
     return LACX_OK;
+}
+static bool block_is_wide(const int32_t* pcm, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i)
+        if (pcm[i] > (1 << 24) || pcm[i] < -(1 << 24)) return true;
+    return false;
 }
 
 static int block_analyze(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
@@ -1999,12 +2008,23 @@ static int block_analyze(lacx_encoder* e, const int32_t* pcm, uint32_t n) {
     HIP_TRY(e, hipSetDevice(e->device), "hipSetDevice");
     rc = upload(e, pcm, nullptr, n);
     if (rc) return rc;
+    if (block_is_wide(pcm, n)) {
+        rc = ensure_workspace(e, 1);
+        if (rc) return rc;
+        if (!e->d_wide) HIP_TRY(e, hipMalloc((void**)&e->d_wide, (size_t)11 * kMaxBlock * sizeof(int32_t)), "hipMalloc(wide residuals)");
+        hipStream_t st = e->stream[0];
+        HIP_TRY(e, launch_wide_block(e->d_left, n, e->cfg.zero_run_enabled ? 1 : 0, e->cfg.partitioning_enabled ? 1 : 0, e->d_wide,
+                                     e->ws.plans, st), "kernel launch");
+        HIP_TRY(e, hipMemcpyAsync(e->h_plans, e->ws.plans, sizeof(ChannelPlan), hipMemcpyDeviceToHost, st), "D2H plan");
+        HIP_TRY(e, hipStreamSynchronize(st), "synchronize");
+        return LACX_OK;
+    }
     return analyze_on_device(e, e->d_left, nullptr, n, 1, 0, /*bit_depth=*/0, e->stream[0]);
 }
 
 int lacx_block_plan_only(lacx_encoder* e, const int32_t* pcm, uint32_t n, lacx_channel_plan* plan) {
     if (!e || !pcm || !plan || n == 0) return LACX_E_INVALID;
-    int rc = block_domain_check(e, pcm, n);
+    int rc = block_size_check(e, n);
     if (rc) return rc;
     rc = block_analyze(e, pcm, n);
     if (rc) return rc;
@@ -2023,15 +2043,22 @@ int lacx_block_encode(lacx_encoder* e, const int32_t* pcm, uint32_t n, uint8_t**
         return LACX_OK;
     }
     if (!pcm) return LACX_E_INVALID;
-    int rc = block_domain_check(e, pcm, n);
+    int rc = block_size_check(e, n);
     if (rc) return rc;
     rc = block_analyze(e, pcm, n);
     if (rc) return rc;
     const ChannelPlan& pl = e->h_plans[0];
-    uint8_t* buf = static_cast<uint8_t*>(std::malloc(pl.payload_bytes ? pl.payload_bytes : 1));
+    // In the wide domain the reference's estimate and its emit disagree at k = 31 (the estimate drops the quotient from
+    // k >= 31 on, Rice::encode from k >= 32: ref block/encoder.cpp:67-70 vs rice/rice.cpp:17-32), so the emitted size may
+    // exceed the plan's there -- the bytes are the reference's either way; inside the validated domain sizes must agree.
+    const bool wide = block_is_wide(pcm, n);
+    if (wide && pl.payload_bytes == 0xFFFFFFFFu) return fail(e, LACX_E_RUNTIME, "encoded block is outside format limits");
+    const size_t cap = (size_t)pl.payload_bytes + (wide ? (size_t)n * 8u + 64u : 0u);
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(cap ? cap : 1));
+    if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
     std::vector<int32_t> scratch(n);
-    const size_t wrote = emit_channel(pl, pcm, nullptr, CH_L, n, buf, pl.payload_bytes, scratch.data());
-    if (wrote != pl.payload_bytes) {
+    const size_t wrote = emit_channel(pl, pcm, nullptr, CH_L, n, buf, cap, scratch.data());
+    if (wrote == (size_t)-1 || (!wide && wrote != pl.payload_bytes)) {
         std::free(buf);
         return fail(e, LACX_E_RUNTIME, "emitted size disagrees with the device plan (internal error)");
     }
@@ -2047,7 +2074,8 @@ int lacx_debug_emit_workers(lacx_encoder* e) { return e ? (int)pool_of(e).thread
 int lacx_debug_lpc(lacx_encoder* e, const int32_t* pcm, uint32_t n, int64_t* acorr, int16_t* coef,
                    uint8_t* used) {
     if (!e || !pcm || n == 0) return LACX_E_INVALID;
-    int rc = block_domain_check(e, pcm, n);
+    if (block_is_wide(pcm, n)) return fail(e, LACX_E_INVALID, "lacx_debug_lpc probes the streaming kernels: samples must lie in the 25-bit mid/side domain");
+    int rc = block_size_check(e, n);
     if (rc) return rc;
     rc = block_analyze(e, pcm, n);
     if (rc) return rc;

@@ -630,3 +630,44 @@ def test_batch_of_streams_is_one_job_with_the_same_bytes(gpu, oracle):
     be2 = gpu.lacx.BatchEncoder([(sr, bd, sm if ch == 2 else 0) for (_, ch, bd, sr, sm, _) in specs[:1]] + [(48000, 16, 2)], device=0)
     with pytest.raises(ValueError, match=r"stream 1: left sample at index 17000 is outside"):
         be2.encode_device(streams[:1] + [(dl.data_ptr(), gpu.lacx.PCM_PLANAR_I32, 2, 20000, dr.data_ptr())])
+
+
+def test_block_encoder_full_int32_domain(gpu, oracle):
+    """Block::Encoder::encode takes any int32 samples (ref block/encoder.cpp:313-316): outside the 25-bit domain of
+    validated input the LPC residual can leave int32 and the reference falls back through the orders {12, 10, 8, 6, 4}
+    to none (ref lpc.cpp:24-36, 188-229), zigzag values use all 32 bits and k saturates at 31.  The wide kernel
+    (csrc/wide.hip) must give the reference's bytes there (oracle: lac_oracle.c:291-343 restates the fallback)."""
+    rng = np.random.default_rng(77)
+    be = gpu.lacx.BlockEncoder(12)
+    cases = []
+    n = 4096
+    t = np.arange(n)
+    # 26..31-bit material: smooth (LPC wins, residuals small), noisy, and mixtures with full-scale steps
+    for bits in (26, 28, 30, 31):
+        amp = (1 << (bits - 1)) - 1
+        cases.append((np.sin(t / 37.0) * amp * 0.9).astype(np.int64))
+        cases.append(rng.integers(-amp, amp, size=n))
+        sq = np.where((t // 64) % 2 == 0, amp, -amp).astype(np.int64)
+        cases.append(sq + rng.integers(-1000, 1000, size=n))
+    # alternating extremes: every difference overflows int32, every LPC order has to fall back
+    alt = np.where(t % 2 == 0, 2**31 - 1, -2**31).astype(np.int64)
+    cases.append(alt)
+    cases.append(np.concatenate([alt[:2000], np.zeros(2096, np.int64)]))
+    # a block that is inside the domain except for one sample
+    one = (np.sin(t / 11.0) * 30000).astype(np.int64)
+    one[1234] = 2**29
+    cases.append(one)
+    # short blocks and a full-size one
+    cases.append(rng.integers(-2**30, 2**30, size=37))
+    cases.append(rng.integers(-2**27, 2**27, size=300))
+    cases.append((np.sin(np.arange(16384) / 90.0) * (2**29)).astype(np.int64) + rng.integers(-2**20, 2**20, size=16384))
+    for i, x in enumerate(cases):
+        x = np.clip(x, -2**31, 2**31 - 1).astype(np.int32)
+        for zr, pt in ((True, True), (False, False)):
+            be.set_zero_run_enabled(zr)
+            be.set_partitioning_enabled(pt)
+            got = be.encode(x)
+            want = oracle.block_encode(x, zr, pt)
+            assert got == want, (i, zr, pt, len(got), len(want))
+    with pytest.raises(ValueError, match="larger than 16384"):
+        be.encode(np.zeros(16385, np.int32))

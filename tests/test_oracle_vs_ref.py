@@ -43,3 +43,24 @@ def test_decoder_roundtrip_and_matches_reference_decoder(pkg, oracle, ref):
     l2, r2, h2 = ref.decode(data)
     assert np.array_equal(l1, left) and np.array_equal(r1, right)
     assert np.array_equal(l1, l2) and np.array_equal(r1, r2) and h1 == h2
+
+
+def test_wide_blocks_oracle_matches_reference(oracle, ref):
+    """Block::Encoder outside the 25-bit domain of validated input: residuals that leave int32 and the order fallback
+    (ref lpc.cpp:24-36, 188-229), 32-bit zigzag values, k = 31.  Pins the oracle where the GPU's wide kernel is checked
+    against it (tests/test_gpu_parity.py::test_block_encoder_full_int32_domain)."""
+    rng = np.random.default_rng(77)
+    n = 4096
+    t = np.arange(n)
+    cases = []
+    for bits in (26, 28, 30, 31):
+        amp = (1 << (bits - 1)) - 1
+        cases.append((np.sin(t / 37.0) * amp * 0.9).astype(np.int64))
+        cases.append(rng.integers(-amp, amp, size=n))
+        cases.append(np.where((t // 64) % 2 == 0, amp, -amp).astype(np.int64) + rng.integers(-1000, 1000, size=n))
+    alt = np.where(t % 2 == 0, 2**31 - 1, -2**31).astype(np.int64)
+    cases += [alt, np.concatenate([alt[:2000], np.zeros(2096, np.int64)]), rng.integers(-2**30, 2**30, size=37)]
+    for i, x in enumerate(cases):
+        x = np.clip(x, -2**31, 2**31 - 1).astype(np.int32)
+        for zr, pt in ((True, True), (False, False)):
+            assert oracle.block_encode(x, zr, pt) == ref.block_encode(x, zr, pt), (i, zr, pt)
