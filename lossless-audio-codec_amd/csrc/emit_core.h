@@ -192,6 +192,21 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, M& sh, const BitTile* tile_in,
     uint32_t s = part * base;
     uint32_t e = (part + 1u == parts) ? n : s + base;
     uint32_t mode = sh.part_mode_k[part] >> 5, k0 = sh.part_mode_k[part] & 31u;
+    if (PASS1) {
+        // Static-Rice partitions (the usual choice: the mode is preferred within 5 %, ref block/encoder.cpp:518) need no
+        // walk: the parameter is the partition's for every sample and the chunk's token bits follow from the thread's
+        // bit-sliced plane counts, sum (u >> k) = sum over the slices l of (cs[l] >> k) << l.  Taken when every lane of
+        // the wave has a complete chunk inside one static partition.
+        const bool whole_static = th.cnt == G::CH && (uint32_t)th.a + (uint32_t)G::CH <= e && mode == 3u;
+        if (wave_all(whole_static)) {
+            uint64_t shifted = 0;
+#pragma unroll
+            for (int l = 0; l < G::LV; ++l) shifted += (uint64_t)(th.cs[l] >> k0) << l;
+#pragma unroll
+            for (int i = 0; i < G::CH; ++i) sh.xp.o.kin[i * G::T + t] = (uint8_t)k0;
+            return shifted + (uint64_t)G::CH * (1u + k0);
+        }
+    }
     // --- state for the Rice parameter (pass 1 only) ---
     uint64_t P = sh.tabP[t];
     uint64_t Pseg = 0, W = 0;
