@@ -35,6 +35,17 @@ struct DeviceWorkspace {
     unsigned long long* stream_pre = nullptr; // [streams] k_offsets: payload prefix at every stream's first block (sets of several streams)
 };
 
+// Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while
+// the analysis runs (one stream).  host_end == nullptr: off.
+struct RangeProgress {
+    uint32_t* range_cnt = nullptr;            // [ranges] device, zeroed per call: indices of the range in place
+    unsigned long long* range_end = nullptr;  // [ranges] device: end offset of the range's last index
+    unsigned long long* host_end = nullptr;   // [ranges] pinned host (device address), zeroed per call: end offset + 1 once complete
+    uint32_t fuse_total = 0;                  // indices that take part (the ranges cover [0, fuse_total))
+    uint32_t fence_mode = 0;                  // diagnostic: 0 system-scope write-back, 1 agent scope, 2 none
+};
+constexpr uint32_t kPackerRangeItems = 256;
+
 // One launch set on the host: the kernel argument plus what the launchers themselves need to know.
 struct LaunchSet {
     BatchRef br;
@@ -108,7 +119,7 @@ hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* 
 // slots of the set's stream indices to their place in `out` as they are published.  counters: [0] error flags, [1] the
 // number of channel blocks it has put in place, [2] packer waves that gave up waiting for a record.
 hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
-                             hipStream_t stream);
+                             hipStream_t stream, const RangeProgress& rp = RangeProgress{});
 
 // The decoder (decode.hip): one lane per block; payload must be followed by kDecodeTailPad readable zero bytes (the bit
 // reader's bounded look-ahead past the last block, see BitIn).

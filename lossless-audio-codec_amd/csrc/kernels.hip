@@ -312,6 +312,7 @@ __device__ __forceinline__ StreamDesc wave_uniform(const StreamDesc& d) {
     return r;
 }
 
+// (per lane: kernels whose lanes work on different blocks -- k_stereo, k_levinson, k_offsets)
 __device__ __forceinline__ StreamDesc stream_of_block(const BatchRef& br, uint32_t gblk) {
     if (br.table == nullptr) return br.single;
     uint32_t lo = 0, hi = br.nstreams;  // invariant: table[lo].first_block <= gblk < table[hi].first_block
@@ -319,7 +320,12 @@ __device__ __forceinline__ StreamDesc stream_of_block(const BatchRef& br, uint32
         const uint32_t mid = (lo + hi) >> 1;
         if (br.table[mid].first_block <= gblk) lo = mid; else hi = mid;
     }
-    return wave_uniform(br.table[lo]);
+    return br.table[lo];
+}
+// (the whole workgroup works on block gblk)
+__device__ __forceinline__ StreamDesc stream_of_block_uniform(const BatchRef& br, uint32_t gblk) {
+    if (br.table == nullptr) return br.single;
+    return wave_uniform(stream_of_block(br, gblk));
 }
 // ... by workgroup of the whole-block analysis grid (channels per block: mono and stereo streams share the grid)
 __device__ __forceinline__ StreamDesc stream_of_workgroup(const BatchRef& br, uint32_t wg) {
@@ -340,7 +346,7 @@ __device__ __forceinline__ StreamDesc stream_of_item(const BatchRef& br, uint32_
         const uint32_t mid = (lo + hi) >> 1;
         if (br.table[mid].prm.stream_base <= item) lo = mid; else hi = mid;
     }
-    return br.table[lo];
+    return wave_uniform(br.table[lo]);  // (callers: one item per workgroup)
 }
 
 __device__ __forceinline__ SlotSrc slot_src(const AnalyzeParams& prm, const int32_t* L, const int32_t* R, int ch) {
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(kIngestThreads, 5) void k_ingest(BatchRef br, unsig
     __shared__ unsigned int s_bad;
     uint32_t blk, chsel;  // blk: global block of the launch set (indexes the workspace)
     xcd_slot(blockIdx.x, 4u, gridDim.x >> 2, blk, chsel);
-    const StreamDesc sd = stream_of_block(br, blk);
+    const StreamDesc sd = stream_of_block_uniform(br, blk);
     const AnalyzeParams prm = sd.prm;
     const int32_t* __restrict__ L = sd.left;
     const int32_t* __restrict__ R = sd.right;
@@ -1398,14 +1404,14 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
     StreamDesc sd;
     if (probe_class) {
         blk = blockIdx.x / 12u;
-        sd = stream_of_block(br, blk);
+        sd = stream_of_block_uniform(br, blk);
         const int s = 4 + (int)(blockIdx.x % 12u);
         if ((need[blk] >> s) & 1u) slot = s;
     } else {
         uint32_t wsel;
         if (which_base) {
             blk = one_block;
-            sd = stream_of_block(br, blk);
+            sd = stream_of_block_uniform(br, blk);
             wsel = blockIdx.x;
         } else {
             sd = stream_of_workgroup(br, blockIdx.x);
@@ -1685,7 +1691,9 @@ __device__ __forceinline__ void copy_slot_out(const uint8_t* __restrict__ src, u
 #ifndef LACX_STREAM_UNROLL
 #define LACX_STREAM_UNROLL 8
 #endif
-constexpr int kStreamGrid = 2;
+constexpr int kStreamGrid = 2;        // packing straight into pinned host memory (PCIe-bound: see above)
+constexpr int kStreamGridDevice = 3;  // packing into device memory that a copy engine drains: three CUs keep up with the analysis
+constexpr uint32_t kRangeItems = 256;  // stream indices per progress range (about 5 MB of 16-bit music)
 constexpr int kStreamThreads = 1024;
 constexpr unsigned long long kStreamTimeoutTicks = 2000000ull;  // 20 ms of the 100 MHz clock without the awaited record
 __global__ __launch_bounds__(kStreamThreads) void k_stream_out(BatchRef br, uint32_t total, int nap,
@@ -1695,7 +1703,8 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream_out(BatchRef br, uint
                                                                const uint8_t* __restrict__ slots, unsigned long long slot_stride,
                                                                uint8_t* __restrict__ out,
                                                                uint32_t* __restrict__ packed, uint32_t* __restrict__ err_flag,
-                                                               uint32_t* __restrict__ moved_total, uint32_t* __restrict__ gave_up) {
+                                                               uint32_t* __restrict__ moved_total, uint32_t* __restrict__ gave_up,
+                                                               RangeProgress rp) {
     // total: stream indices of the set (all streams).  In a set of several streams every stream's payload has its own
     // region of the result buffer and its own running offset; item_stream[i] = the stream of index i (null: one stream).
     const int lane = threadIdx.x & 63;
@@ -1705,6 +1714,29 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream_out(BatchRef br, uint
     uint32_t summed = br.table ? 0u : br.single.prm.stream_base;
     uint32_t cur_first = summed;     // first stream index of the stream `running` belongs to
     uint32_t moved = 0;  // stream indices this wave has put in place
+    // Progress for the host (one stream, device destination that a copy engine drains while the analysis goes on): the
+    // indices come in ranges of kRangeItems; a wave's indices are `units` apart, so it has a handful per range.  When it
+    // leaves a range it writes its stores back to memory -- a copy engine does not look into the L2 -- and adds its count
+    // to the range's; the wave that completes the count publishes the range's end offset (left by the wave that moved
+    // the range's last index) to the host.
+    uint32_t pend_range = 0xFFFFFFFFu, pend_count = 0;
+    auto flush_progress = [&]() {
+        if (pend_count == 0u) return;  // wave-uniform
+        if (rp.fence_mode == 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: s_waitcnt + L2 write-back
+        else if (rp.fence_mode == 1u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const uint32_t r = pend_range;
+            const uint32_t last = (r + 1u) * kRangeItems - 1u < rp.fuse_total - 1u ? (r + 1u) * kRangeItems - 1u : rp.fuse_total - 1u;
+            const uint32_t in_range = last - r * kRangeItems + 1u;
+            const uint32_t before = __hip_atomic_fetch_add(&rp.range_cnt[r], pend_count, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + pend_count == in_range) {
+                const unsigned long long end = __hip_atomic_load(&rp.range_end[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&rp.host_end[r], end + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        pend_count = 0;
+    };
     for (uint32_t i = unit; i < total; i += units) {
         const StreamDesc sd = br.table ? br.table[item_stream[i]] : br.single;
         const uint32_t first = sd.prm.stream_base;
@@ -1766,14 +1798,28 @@ __global__ __launch_bounds__(kStreamThreads) void k_stream_out(BatchRef br, uint
                 if (lane == 0) atomicOr(err_flag, 2u);
             } else {
                 uint8_t* dst = out + sd.out_base + off;
-                if (flag_byte && lane == 0) dst[0] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
                 const uint32_t fb = flag_byte ? 1u : 0u;
+                if (flag_byte && lane == 0) dst[0] = (rec & kRecMs) ? 1 : 0;  // per-block flag (ref lac/encoder.cpp:363)
                 copy_slot_out<64, LACX_STREAM_UNROLL>(slots + (unsigned long long)i * slot_stride, dst + fb, (uint32_t)bytes - fb, lane);
                 if (lane == 0) packed[i] = 1u;
                 ++moved;
             }
+        } else if (lane == 0) {
+            atomicOr(err_flag, 4u);  // nothing came from the analysis kernel for this index: its bytes arrive later (k_emit)
+        }
+        // Progress for the host (one stream, device destination): see flush_progress.
+        if (rp.host_end) {
+            const uint32_t r = i / kRangeItems;
+            if (r != pend_range) {
+                flush_progress();
+                pend_range = r;
+            }
+            const uint32_t last_of_range = (r + 1u) * kRangeItems - 1u < rp.fuse_total - 1u ? (r + 1u) * kRangeItems - 1u : rp.fuse_total - 1u;
+            if (i == last_of_range && lane == 0) __hip_atomic_store(&rp.range_end[r], running, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++pend_count;
         }
     }
+    flush_progress();
     // k_pack / k_emit behind this kernel return at once when every channel block of the shard was moved here
     if (lane == 0 && moved) atomicAdd(moved_total, moved);
 }
@@ -1930,16 +1976,17 @@ hipError_t launch_gather(const GatherList& g, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static_assert(kRangeItems == kPackerRangeItems, "host and device agree on the range size");
 hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
-                             hipStream_t stream) {
+                             hipStream_t stream, const RangeProgress& rp) {
     if (ls.total_items == 0) return hipSuccess;
-    int nap = 1, grid = kStreamGrid;  // tuning knobs
+    int nap = 1, grid = rp.host_end ? kStreamGridDevice : kStreamGrid;  // tuning knobs
     if (const char* v = std::getenv("LACX_PACK_NAP")) nap = std::atoi(v) > 0 ? std::atoi(v) : 1;
     if (const char* v = std::getenv("LACX_PACK_GRID")) grid = std::atoi(v) > 0 ? std::atoi(v) : grid;
     // counters: [0] error flags, [1] channel blocks put in place, [2] packer waves that gave up waiting
     hipLaunchKernelGGL(k_stream_out, dim3((uint32_t)grid), dim3(kStreamThreads), 0, stream, ls.br, ls.total_items, nap, ls.item_stream,
                        (const unsigned long long*)ws.size_rec, (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots,
-                       ws.slot_stride, out, ws.packed, counters, counters + 1, counters + 2);
+                       ws.slot_stride, out, ws.packed, counters, counters + 1, counters + 2, rp);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -65,6 +66,8 @@ struct lacx_encoder {
         int channels = 0;
         bool staged = false;
         bool fused = false;
+        bool drained = false;     // packer -> d_payload, copy engine -> h_payload (see h_range)
+        uint32_t ranges = 0;
         hipStream_t st[4] = {};
         clk::time_point t0;
         // inputs of the call, kept for the re-emit after a too-small result reservation
@@ -101,6 +104,14 @@ struct lacx_encoder {
     uint8_t* d_batch = nullptr;
     size_t d_batch_cap = 0;
     int32_t* d_wide = nullptr;  // lacx_block_encode outside the 25-bit domain: the eleven candidate residuals (wide.hip)
+    // Copy-engine drain of the payload (one-stream encodes): the packer packs into d_payload (HBM) and reports complete
+    // ranges in h_range (pinned); encode_device_end lets a copy engine fetch them while the analysis still runs.
+    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream2 = nullptr;  // (ranges alternate between two streams: the next copy's set-up overlaps the current one's transfer)
+    unsigned long long* h_range = nullptr;  // pinned, [h_range_cap]
+    uint32_t h_range_cap = 0;
+    uint32_t* d_range_cnt = nullptr;        // device, inside zero_region
+    unsigned long long* d_range_end = nullptr;
     std::unique_ptr<EmitPool> pool;
     std::string err;
     lacx_timing timing{};
@@ -187,6 +198,8 @@ int ensure_device(lacx_encoder* e) {
         HIP_TRY(e, hipStreamCreateWithPriority(&e->pack_stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
     }
     HIP_TRY(e, hipEventCreateWithFlags(&e->pack_done, hipEventDisableTiming), "hipEventCreate");
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking), "hipStreamCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_tspan, sizeof(unsigned long long) * 2 * kMaxChunks, 0), "hipHostMalloc");
     e->device_ready = true;
     return LACX_OK;
@@ -241,8 +254,10 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         // and flags of the fused emit (per channel block of the shard), the error flags, the kernel time stamps.
         {
             const size_t items = (size_t)nblocks * 2 + 4;
+            const size_t ranges = items / kPackerRangeItems + 2;  // packer progress (copy-engine drain)
             const size_t bytes = items * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) +
-                                 sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 4);
+                                 sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 4) +
+                                 ranges * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16;
             e->zero_bytes = (bytes + 15) & ~(size_t)15;
             HIP_TRY(e, hipMalloc((void**)&e->zero_region, e->zero_bytes), "hipMalloc(zeroed region)");
             uint8_t* p = e->zero_region;
@@ -257,6 +272,11 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             e->ws.packed = reinterpret_cast<uint32_t*>(p);
             p += items * sizeof(uint32_t);
             e->ws.err_flag = reinterpret_cast<uint32_t*>(p);
+            p += sizeof(uint32_t) * (kMaxChunks + 4);
+            p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 7) & ~(uintptr_t)7);
+            e->d_range_end = reinterpret_cast<unsigned long long*>(p);
+            p += ranges * sizeof(unsigned long long);
+            e->d_range_cnt = reinterpret_cast<uint32_t*>(p);
         }
         e->ws_blocks = nblocks;
     }
@@ -730,6 +750,28 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         const char* v = std::getenv("LACX_EMIT_STAGED");
         return v && *v && *v != '0';
     }();
+    // Default with the fused emit: the packer packs into device memory and a copy engine drains it (LACX_DIRECT_PACKER=1:
+    // the packer's CUs store straight into pinned host memory, the round-2 layout).
+    const bool drained = !staged && !(std::getenv("LACX_FUSED_EMIT") && *std::getenv("LACX_FUSED_EMIT") == '0') &&
+                         !std::getenv("LACX_DIRECT_PACKER") && !std::getenv("LACX_NO_PACKER") && !std::getenv("LACX_PINNED_CAP_BYTES");
+    if (drained) {
+        const uint64_t dev_cap = pinned_reservation(e, frames, channels, nb) + 64ull;
+        if (dev_cap > e->d_payload_cap) {
+            if (e->d_payload) (void)hipFree(e->d_payload);
+            e->d_payload = nullptr;
+            e->d_payload_cap = 0;
+            HIP_TRY(e, hipMalloc((void**)&e->d_payload, dev_cap), "hipMalloc(payload)");
+            e->d_payload_cap = dev_cap;
+        }
+        const uint32_t ranges = (nb * (uint32_t)channels + kPackerRangeItems - 1u) / kPackerRangeItems + 1u;
+        if (ranges > e->h_range_cap) {
+            if (e->h_range) (void)hipHostFree(e->h_range);
+            e->h_range = nullptr;
+            e->h_range_cap = 0;
+            HIP_TRY(e, hipHostMalloc((void**)&e->h_range, (size_t)ranges * sizeof(unsigned long long), 0), "hipHostMalloc(ranges)");
+            e->h_range_cap = ranges;
+        }
+    }
     if (staged) {
         const uint64_t dev_cap = payload_upper_bound(frames, channels, nb) + 64ull;
         if (dev_cap > e->d_payload_cap) {
@@ -760,12 +802,15 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     reset_device_timing(e);
     e->timing.emit_ms = 0;
     const auto t0 = clk::now();
+    for (int c = 0; c < kMaxChunks; ++c) e->h_totals[c] = 0;  // (the last chunk's total doubles as the "all kernels done" word)
     hipStream_t st[kStreams];
     for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
     if (user_stream) st[0] = user_stream;
     uint8_t* emit_dst = e->d_payload;
     uint64_t emit_cap = e->d_payload_cap;
-    if (!staged) {
+    if (drained) {
+        emit_cap = std::min<uint64_t>(e->d_payload_cap, e->h_payload_cap);
+    } else if (!staged) {
         HIP_TRY(e, hipHostGetDevicePointer((void**)&emit_dst, e->h_payload, 0), "hipHostGetDevicePointer");
         emit_cap = e->h_payload_cap;
     }
@@ -840,7 +885,20 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
             AnalyzeParams shard_prm = make_params(e, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
             shard_prm.stream_base = 0;
             LaunchSet shard = one_stream_set(shard_prm, nullptr, nullptr, fuse_items, emit_cap);
-            HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
+            RangeProgress rp;
+            if (drained) {
+                const uint32_t ranges = (fuse_items + kPackerRangeItems - 1u) / kPackerRangeItems;
+                std::memset(e->h_range, 0, (size_t)ranges * sizeof(unsigned long long));
+                // (the range counters live in the region the call's one memset clears: a memset on the packer's own stream
+                // would make the packer's dispatch wait for everything queued before it, the analysis kernel included)
+                rp.range_cnt = e->d_range_cnt;
+                rp.range_end = e->d_range_end;
+                HIP_TRY(e, hipHostGetDevicePointer((void**)&rp.host_end, e->h_range, 0), "hipHostGetDevicePointer");
+                rp.fuse_total = fuse_items;
+                if (const char* fm = std::getenv("LACX_DRAIN_FENCE")) rp.fence_mode = (uint32_t)std::atoi(fm);
+                e->pend.ranges = ranges;
+            }
+            HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream, rp), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
         }
     }
@@ -896,6 +954,8 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     e->pend.channels = channels;
     e->pend.staged = staged;
     e->pend.fused = fused;
+    e->pend.drained = drained;  // (the result is fetched from the device payload even when no range was ever reported)
+    if (!(drained && fused && fuse_items != 0)) e->pend.ranges = 0;
     for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
     e->pend.t0 = t0;
     e->pend.d_left = d_left;
@@ -958,6 +1018,41 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     uint64_t off = 0;
     int status = LACX_OK;
     size_t copies = 0;
+    // Copy-engine drain: while the kernels run, every range of stream indices the packer reports complete is fetched
+    // from the device payload into the pinned result buffer (hipMemcpyAsync on its own stream: a copy engine, not CUs).
+    uint64_t drained_to = 0;
+    static const bool dbg_drain = std::getenv("LACX_DEBUG_DRAIN") != nullptr;
+    static const bool two_streams = std::getenv("LACX_ONE_COPY_STREAM") == nullptr;
+    if (e->pend.drained) {
+        uint32_t next = 0;
+        const volatile unsigned long long* flags = e->h_range;
+        auto pump = [&]() {
+            while (next < e->pend.ranges) {
+                const unsigned long long v = flags[next];
+                if (v == 0) break;
+                const uint64_t end = v - 1u;
+                if (dbg_drain) std::fprintf(stderr, "[drain] range %u end %llu at %.3f ms\n", next, (unsigned long long)end, ms_since(t0));
+                if (end > drained_to && end <= e->h_payload_cap) {
+                    if (hipMemcpyAsync(e->h_payload + drained_to, e->d_payload + drained_to, end - drained_to, hipMemcpyDeviceToHost,
+                                       (next & 1u) && two_streams ? e->copy_stream2 : e->copy_stream) != hipSuccess)
+                        return;  // (the final copy below fetches what is missing)
+                    drained_to = end;
+                }
+                ++next;
+            }
+        };
+        // (no runtime call in the loop but the copies: the gather kernel -- the last one of the call -- stores the
+        // cumulative byte count of the last chunk, non-zero, into pinned memory that was zeroed before the launch)
+        const volatile unsigned long long* finished = &e->h_totals[chunks.size() - 1];
+        const auto poll0 = clk::now();
+        while (*finished == 0ull) {
+            pump();
+            if (ms_since(poll0) > 20000.0) break;  // (a lost device: the event wait below reports it)
+        }
+        if (dbg_drain) std::fprintf(stderr, "[drain] kernels done at %.3f ms, copy stream %s\n", ms_since(t0),
+                                    hipStreamQuery(e->copy_stream) == hipSuccess ? "idle" : "busy");
+        pump();
+    }
     for (size_t c = 0; c < chunks.size(); ++c) {
         const hipError_t he = hipEventSynchronize(e->done[c]);
         if (he != hipSuccess) {
@@ -993,6 +1088,22 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         off = end;
     }
     for (size_t c = 0; c < copies; ++c) (void)hipEventSynchronize(e->done[c]);
+    if (e->pend.drained) {
+        if (status == LACX_OK) {
+            // what the ranges did not cover: the tail, and -- when the repair kernels had to place anything the packer had
+            // counted as done (never seen) -- everything
+            if (e->h_err[kMaxChunks] & 4u) drained_to = 0;
+            if (off > drained_to) {
+                const hipError_t ce = hipMemcpyAsync(e->h_payload + drained_to, e->d_payload + drained_to, off - drained_to,
+                                                     hipMemcpyDeviceToHost, e->copy_stream);
+                if (ce != hipSuccess) status = hip_fail(e, ce, "D2H payload");
+            }
+        }
+        hipError_t se = hipStreamSynchronize(e->copy_stream);
+        const hipError_t se2 = hipStreamSynchronize(e->copy_stream2);
+        if (se == hipSuccess) se = se2;
+        if (se != hipSuccess && status == LACX_OK) status = hip_fail(e, se, "D2H payload");
+    }
     if (status == -1 && !staged) {
         // no sample-range error can hide behind the overflow: wait for every chunk's block plans first
         (void)hipDeviceSynchronize();
@@ -1171,6 +1282,9 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     if (tab_bytes + map_bytes > e->d_batch_cap) {
         if (e->d_batch) (void)hipFree(e->d_batch);
         if (e->d_wide) (void)hipFree(e->d_wide);
+        if (e->h_range) (void)hipHostFree(e->h_range);
+        if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+        if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
         e->d_batch = nullptr;
         e->d_batch_cap = 0;
         HIP_TRY(e, hipMalloc((void**)&e->d_batch, tab_bytes + map_bytes), "hipMalloc(batch table)");

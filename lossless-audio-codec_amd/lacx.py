@@ -613,4 +613,23 @@ class BatchEncoder:
         rc = lib().lacx_encode_batch_device(h, items, C.c_uint32(n), C.c_void_p(stream), outs)
         if rc != OK:
             _raise(h, rc)
-        return [(PayloadView(o.payload, o.payload_size), np.ctypeslib.as_array(o.table, shape=(o.nblocks, 2))) for o in outs]
+        return [(PayloadView(o.payload, o.payload_size), TableView(o.table, o.nblocks)) for o in outs]
+
+
+class TableView:
+    """Borrowed view of a block table (frames, bytes per block) in encoder-owned pinned memory; converted to a numpy array
+    only when asked (a batch of many streams returns one per stream on every call)."""
+
+    def __init__(self, ptr, nblocks):
+        self._ptr = ptr
+        self.shape = (int(nblocks), 2)
+
+    def array(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self._ptr, shape=self.shape)
+
+    def copy(self) -> np.ndarray:
+        return self.array().copy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.array()
+        return a.astype(dtype) if dtype is not None and a.dtype != dtype else a
