@@ -21,7 +21,7 @@
 // 256/CH resp. 96/CH words to the left).
 //
 // The functions here are plain per-thread code (no cross-lane operations) so that the same text is
-// compiled into the HIP kernel (kernels.hip) and into the lock-step host simulator used by the CPU
+// compiled into the HIP kernel (k_analyze.hip) and into the lock-step host simulator used by the CPU
 // tests (tests/native/sim_analyze.cpp).  Cross-thread steps (block scans, ballots, LDS atomics) live in
 // the drivers.
 #pragma once

@@ -384,7 +384,7 @@ struct EmitPool::Impl {
 
 EmitPool::EmitPool(unsigned threads) : impl_(new Impl) {
     // `threads` extra workers, exactly: 0 means none (finish() runs the job on the calling thread, which is always
-    // the last worker).  "Auto" is resolved by the callers (pool_of in lacx_api.cpp, emit_blocks below).
+    // the last worker).  "Auto" is resolved by the callers (pool_of in api_core.cpp, emit_blocks below).
     impl_->workers.reserve(threads);
     for (unsigned t = 0; t < threads; ++t) impl_->workers.emplace_back([this] { impl_->worker_main(); });
 }

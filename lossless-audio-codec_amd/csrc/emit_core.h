@@ -8,7 +8,7 @@
 //      constant for static-Rice partitions) -- stored as one byte per sample, and the thread's token bits;
 //   3. block scan of the bit counts -> every thread's bit offset;
 //   4. walk 2: tokens OR-ed MSB-first into an LDS tile (big-endian words), tile copied out.
-// As in analyze_core.h these are plain per-thread functions, shared by the HIP kernel (kernels.hip) and the
+// As in analyze_core.h these are plain per-thread functions, shared by the HIP kernels (emit_device.h) and the
 // host simulator (tests/native/sim_analyze.cpp); cross-thread steps live in the drivers.
 #pragma once
 #include "analyze_core.h"

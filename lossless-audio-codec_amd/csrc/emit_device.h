@@ -1,0 +1,171 @@
+// emit_device.h -- the device emit of one channel block (walks of emit_core.h + block scans + tile copy-out), shared by
+// the emit fused into the whole-block analysis kernel (k_analyze.hip) and the stand-alone / repair kernel k_emit
+// (k_emit.hip).  Device code only.
+#pragma once
+#include "device_util.h"
+#include "emit_core.h"
+
+namespace lacx {
+
+// suffix-min scan of tabNX (first non-zero index per chunk) -> exclusive: min over later chunks
+template <class G, class M>
+__device__ __forceinline__ int32_t scan_nx_part1(M& sh, int tid, int32_t* wtot) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t v = sh.tabNX[tid];
+    int32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc = o < inc ? o : inc;
+    }
+    if (lane == 0) wtot[wave] = inc;
+    return inc;
+}
+
+template <class G, class M>
+__device__ __forceinline__ void scan_nx_part2(M& sh, int tid, int32_t inc, const int32_t* wtot, int32_t n) {
+    constexpr int NW = G::T / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    int32_t later = n;
+    for (int w = wave + 1; w < NW; ++w) later = wtot[w] < later ? wtot[w] : later;
+    int32_t next = __shfl_down(inc, 1, 64);
+    if (lane == 63) next = n;
+    sh.tabNX[tid] = next < later ? next : later;
+}
+
+
+// Emit of one channel block from the residual in sh.u (plain zigzag values, block scans of tabP / tabNZ / tabNX done,
+// plan fields loaded): walk 1 (Rice parameter per sample + token bits), bit offsets, walk 2 into 48 KiB LDS tiles,
+// copy-out.  `resolve` is called once by all threads (it may contain barriers) before the first byte leaves the
+// workgroup and yields the address the channel block's bitstream goes to; false from it abandons the emit.  Returns
+// true when the whole bitstream was written.  Shared by k_emit and the emit fused into the analysis kernel.
+template <class G, class M, class Resolve>
+__device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint8_t* __restrict__ out,
+                                          uint32_t* __restrict__ err_flag, Resolve&& resolve, const int tid,
+                                          const bool ablate_stores, const uint32_t slot_bytes STAMP_PARAMS) {
+    (void)out;
+    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
+    if (adaptive0) {
+        if (narrow) {
+            phase_a<G, true>(th, sh);
+        } else {
+            phase_a<G, false>(th, sh);
+        }
+        __syncthreads();
+    }
+    STAMP(25);
+    auto orw = [](uint32_t* w, uint32_t v) { atomicOr(w, v); };
+    auto stw = [](uint32_t* w, uint32_t v) { *w = v; };
+    // walk 1: Rice parameter per sample + token bits of the chunk
+    const unsigned long long mybits = narrow ? emit_walk<G, true>(th, sh, nullptr, 0, orw, stw)
+                                             : emit_walk<G, false>(th, sh, nullptr, 0, orw, stw);
+    STAMP(26);
+    __syncthreads();  // every thread is done with the sample prefix sums: tabP becomes the bit-offset table
+    sh.tabP[tid] = mybits;
+    {
+        // sum scan of the bit counts (tabP only)
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long inc = wave_scan_add_u64(mybits);
+        if (lane == 63) sh.wtotP[wave] = inc;
+        __syncthreads();
+        unsigned long long base = 0;
+        for (int w = 0; w < wave; ++w) base += sh.wtotP[w];
+        sh.tabP[tid] = base + inc - mybits;
+        if (tid == G::T - 1) sh.tabP[G::T] = base + inc;
+        __syncthreads();
+    }
+    const unsigned long long total_bits = sh.tabP[G::T] + sh.header_bits;
+    const unsigned long long nbytes = (total_bits + 7u) >> 3;
+    if (tid == 0 && (nbytes != sh.payload_bytes || sh.err)) atomicOr(err_flag, 1u);
+    if (nbytes != sh.payload_bytes || sh.err) return false;  // uniform: never write outside the planned byte range
+    const unsigned long long mypos = sh.tabP[tid] + sh.header_bits;
+    STAMP(27);
+
+    // walk 2: tokens into 48 KiB LDS tiles, copied out tile by tile
+    uint8_t* base = nullptr;
+    for (unsigned long long bit0 = 0; bit0 < nbytes * 8u; bit0 += (unsigned long long)kEmitTileWords * 32u) {
+        if (bit0 != 0) lds_barrier();  // every thread has copied its part of the previous tile out of LDS
+        {
+            // only the words this tile's bytes occupy (+ what the 16-byte copy-out may read past them)
+            const unsigned long long left_bytes = nbytes - (bit0 >> 3);
+            const int zw = left_bytes >= (unsigned long long)kEmitTileWords * 4u ? kEmitTileWords
+                                                                                 : (int)((((uint32_t)left_bytes + 15u) >> 4) * 4u + 8u);
+            const int zero_words = zw < kEmitTileWords ? zw : kEmitTileWords;
+            for (int i = tid; i < zero_words; i += G::T) sh.xp.o.obits[i] = 0;
+        }
+        lds_barrier();
+        STAMP(28);
+        BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
+        if (bit0 == 0) emit_header(th, sh, &tile, orw);
+        const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
+        if (mypos < tile_end && mypos + mybits > bit0) {
+            if (narrow) {
+                emit_walk<G, true>(th, sh, &tile, mypos, orw, stw);
+            } else {
+                emit_walk<G, false>(th, sh, &tile, mypos, orw, stw);
+            }
+        }
+        STAMP(29);
+        lds_barrier();
+        STAMP(30);
+        if (bit0 == 0 && !resolve(&base)) return false;  // uniform
+        const unsigned long long byte0 = bit0 >> 3;
+        const unsigned long long left = nbytes - byte0;
+        const uint32_t count = left < (unsigned long long)kEmitTileWords * 4u ? (uint32_t)left : (uint32_t)kEmitTileWords * 4u;
+        // Copy-out in 16-byte stores on 16-byte boundaries of the destination (which may be pinned host
+        // memory behind PCIe: whole, aligned segments matter there); the unaligned head and tail go bytewise.
+        uint8_t* dst = base + byte0;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        const uint32_t head = mis ? (16u - mis < count ? 16u - mis : count) : 0u;
+        const uint32_t nvec = (count - head) >> 4;
+        const uint32_t* tw = sh.xp.o.obits;
+        auto tile_byte = [&](uint32_t i) { return (uint8_t)(tw[i >> 2] >> (24u - 8u * (i & 3u))); };
+        if (ablate_stores) continue;  // timing ablation only (LACX_DEBUG_SKIP bit 11)
+        if (slot_bytes) {
+            // Staging slot (16-byte aligned, padded): whole 16-byte vectors only, stored write-through (sc1) so that
+            // the hand-off to the streaming packer needs no release fence (cdna_hip_programming.md, Guideline 16, R1).
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)slot_bytes, 0x00020000);
+            const uint32_t nv = (count + 15u) >> 4;
+            for (uint32_t v = tid; v < nv; v += G::T) {
+                u32x4 o;
+                o.x = __builtin_bswap32(tw[4u * v]);
+                o.y = __builtin_bswap32(tw[4u * v + 1u]);
+                o.z = __builtin_bswap32(tw[4u * v + 2u]);
+                o.w = __builtin_bswap32(tw[4u * v + 3u]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (int)((uint32_t)byte0 + 16u * v), 0, 16 /* sc1 */);
+            }
+            continue;
+        }
+        if ((uint32_t)tid < head) dst[tid] = tile_byte((uint32_t)tid);
+        {
+            const uint32_t r = head & 3u, j0 = head >> 2;
+            uint4* vdst = reinterpret_cast<uint4*>(dst + head);
+            for (uint32_t v = tid; v < nvec; v += G::T) {
+                const uint32_t j = j0 + 4u * v;
+                uint32_t w[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const uint32_t jj = j + q < (uint32_t)kEmitTileWords ? j + q : (uint32_t)kEmitTileWords - 1u;
+                    w[q] = __builtin_bswap32(tw[jj]);  // bytes of the stream in memory order
+                }
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbyte(w[1], w[0], r);
+                o.y = __builtin_amdgcn_alignbyte(w[2], w[1], r);
+                o.z = __builtin_amdgcn_alignbyte(w[3], w[2], r);
+                o.w = __builtin_amdgcn_alignbyte(w[4], w[3], r);
+                vdst[v] = o;
+            }
+        }
+        {
+            const uint32_t t0 = head + (nvec << 4);
+            if (t0 + (uint32_t)tid < count) dst[t0 + tid] = tile_byte(t0 + (uint32_t)tid);
+        }
+        // no barrier and no wait for the stores here: the workgroup may retire while they are still on their way
+        STAMP(31);
+    }
+    return true;
+}
+
+}  // namespace lacx

@@ -1,0 +1,706 @@
+// k_analyze.hip -- the whole-block / probe analysis kernel and the launcher of the analysis pipeline.
+//   k_analyze<4,64>     one wave per probe slot of an "uncertain" block (ref lac/encoder.cpp:341-354)
+//   k_analyze<16,1024>  one 1024-thread workgroup per needed whole-block slot
+//                                                           (ref block/encoder.cpp:313-552)
+//                       + the bit emit of its channel block into a staging slot (ref block/encoder.cpp:554-838)
+// Pipeline per launch set (launch_analysis): k_ingest, k_stereo, k_levinson (k_front.hip), k_analyze<4,64>, k_decide(1),
+// k_analyze<16,1024> [+ two workgroups per small final block, k_decide(2)]; beside the whole-block kernel, on its own
+// stream, the streaming packer k_stream_out; behind it k_offsets, k_pack, k_emit, k_gather (k_emit.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <mutex>
+
+#include "emit_device.h"
+#include "kernels_internal.h"
+
+namespace lacx {
+
+#ifdef LACX_STAMPS
+__device__ unsigned long long g_stamp_acc[40];
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Fused emit + streaming packer.
+// The whole-block analysis kernel emits a channel block's bitstream right after its plan is final, while the winner's
+// residual (plain, in sh.u) and its block scans are still in LDS -- no re-staging of the PCM, no second residual pass.
+// Where the bytes belong in the shard payload depends on the sizes of all earlier channel blocks, so the workgroup
+// writes them to the channel block's staging slot in device memory (fixed stride, 16-byte aligned) and retires: no
+// analysis workgroup ever waits for another one.  A small companion kernel, k_stream_out, runs beside the analysis
+// on its own stream: it walks the stream indices in order, waits for each slot to be published, keeps the running
+// byte offset and copies slot after slot to its place in the payload (pinned host memory: the bytes cross PCIe while
+// later blocks are still being analysed, nothing is left to copy when the analysis ends).
+// Hand-off per stream index i (= block * channels + channel), two 8-byte words, each written by ONE agent-scope store:
+//   size_rec[i]  = 1 << 62 | ms << 61 | flag byte in front << 60 | bytes
+//                                                 as soon as the plan is final (the data is the flag: R2 granule of
+//                                                 MI355X_MICROARCH.md, no fence needed)
+//   ready_rec[i] = 1  the bitstream is in slot i: the slot is written with write-through (sc1) stores and announced
+//                     behind every storing wave's s_waitcnt vmcnt(0) and the workgroup barrier (cdna_hip_programming.md,
+//                     Guideline 16, R1); the consumer polls relaxed, then fences with an agent-scope acquire before
+//                     it reads the slot;
+//                  2  no bitstream will come from the analysis kernel (left to k_emit).
+// Every wait of the packer is bounded; when it gives up, or for anything it did not move, k_pack / k_emit finish the
+// job after the analysis (they always run), so no dispatch order or co-residency is assumed for correctness.
+// ---------------------------------------------------------------------------------------------
+// idx: stream index of this channel block; flag_byte: the block's LR/MS flag byte precedes this channel block.
+template <class G>
+__device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const AnalyzeParams& prm, const FuseArgs& fa,
+                                           const long long idx, const bool flag_byte, const uint32_t flag_value,
+                                           const int tid STAMP_PARAMS) {
+    const uint32_t n = th.n;
+    // Optimisation barrier on the thread's coordinates: without it the compiler computes the LDS addresses of the emit
+    // phases at kernel entry and keeps them alive (spilled to scratch) through the whole analysis.
+    asm volatile("" : "+v"(th.tid), "+v"(th.a));
+    const unsigned long long my_size = (unsigned long long)sh.plan.payload_bytes + (flag_byte ? 1u : 0u);
+    // the size is final: publish it at once (the packer can account for this block while it is being emitted)
+    if (tid == 0) rec_store(&fa.size_rec[idx], kRecValid | (flag_value ? kRecMs : 0ull) | (flag_byte ? kRecFlag : 0ull) | my_size);
+    // a bitstream longer than the slot (never seen: it would take > 3 resp. 5 bytes per sample) is left to k_emit;
+    // test hook (LACX_DEBUG_SKIP bit 10): so is every fifth channel block
+    const bool skip = (unsigned long long)sh.plan.payload_bytes + 16u > fa.slot_stride ||
+                      ((prm.debug_skip & 1024u) && (idx % 5 == 3));
+    bool done = false;
+    if (!skip) {  // uniform
+        emit_load_plan(sh, sh.plan, tid, G::T);
+        __syncthreads();
+        // the "first non-zero sample after me" table is only read by zero-run partitions (mode 1)
+        if (sh.plan_any_zr) {  // uniform
+            emit_first_nonzero(th, sh);
+            const int32_t nxinc = scan_nx_part1<G>(sh, tid, sh.wx);
+            __syncthreads();
+            scan_nx_part2<G>(sh, tid, nxinc, sh.wx, (int32_t)n);
+            __syncthreads();
+        }
+        uint8_t* slot = fa.slots + (unsigned long long)idx * fa.slot_stride;
+        STAMP(24);
+        done = emit_body<G>(sh, th, n, slot, fa.err_flag, [slot](uint8_t** o) { *o = slot; return true; }, tid,
+                            (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride STAMP_ARGS);
+    }
+    // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
+    // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (done) fa.emitted[idx] = 2u;  // for the kernels that run after this one (k_pack)
+        // test hook (bit 13): the slot is filled but never announced, so the packer gives up and k_pack takes over
+        if (!(prm.debug_skip & 8192u)) rec_store(&fa.ready_rec[idx], done ? 1ull : 2ull);
+    }
+}
+
+// Candidate scoring (ref block/encoder.cpp:337-359) by the 64 lanes of one wave; same result as score_candidate() of
+// analyze_core.h, which one thread computes in a serial chain of ~150 dependent 64-bit operations while fifteen
+// waves wait for it at the next barrier.  Static Rice cost at k: sum_j (u_j >> k) = T_k >> k with
+// T_k = sum_{b >= k} C_b << b, a suffix sum over the bit-plane counts: lane l takes plane 29 - l, one prefix scan gives
+// every T_k, lanes 14..29 hold k = 15..0; the (cost, k) minimum with ties to the lower k is a minimum of cost * 16 + k.
+template <class G>
+__device__ __forceinline__ void score_candidate_wave(Smem<G>& sh, int cand, uint32_t n, int zero_run, uint32_t k0,
+                                                     const uint32_t* planeTot, const unsigned long long* acc, int lane,
+                                                     bool ksums) {
+    uint64_t key = ~0ull;
+    if (ksums) {  // planeTot[k] = sum_j (u_j >> k) already (ksums_wave)
+        if (lane < 16) key = (((uint64_t)planeTot[lane] + (uint64_t)n * (uint64_t)(1 + lane)) << 4) | (uint64_t)lane;
+    } else {
+        const int b = 29 - lane;
+        const uint64_t w = (lane < 30) ? ((uint64_t)planeTot[b] << b) : 0ull;
+        const uint64_t tk = wave_scan_add_u64(w);  // lane l: T_(29-l)
+        if (lane >= 14 && lane < 30) key = (((tk >> b) + (uint64_t)n * (uint64_t)(1 + b)) << 4) | (uint64_t)b;  // cost < 2^45
+    }
+    const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
+    if (lane == 0) {
+        const uint64_t sbits = best_key >> 4;
+        const uint32_t sk = (uint32_t)(best_key & 15u);
+        const uint64_t rice = acc[0], bin = acc[1];
+        const uint32_t hasrun = acc[3] != 0;
+        const uint64_t zr = (zero_run && hasrun) ? acc[2] : rice;
+        const uint64_t a = rice < sbits ? rice : sbits;
+        const uint64_t c = zr < bin ? zr : bin;
+        const uint64_t best = a < c ? a : c;
+        if (sh.best_cand < 0 || best < sh.best_bits || (best == sh.best_bits && cand < sh.best_cand)) {
+            sh.best_cand = cand;
+            sh.best_bits = best;
+            sh.best_rice = rice;
+            sh.best_zr = zr;
+            sh.best_bin = bin;
+            sh.best_static = sbits;
+            sh.best_k0 = k0;
+            sh.best_sk = sk;
+            sh.best_hasrun = hasrun;
+        }
+    }
+}
+
+// estimate_initial_k (ref block/encoder.cpp:121-158) from the plane counts of the first min(256, n) samples, by the 64
+// lanes of one wave (same suffix-sum formulation as score_candidate_wave; k = 0..12, ties to the lower k).
+__device__ __forceinline__ uint32_t initial_k_wave(const uint32_t* planes256, uint32_t n, int lane, bool ksums) {
+    const uint32_t m = n < 256u ? n : 256u;
+    uint64_t key = ~0ull;
+    if (ksums) {  // planes256[k] = sum over the first min(256, n) samples of u >> k (ksums_wave)
+        if (lane <= 12) key = (((uint64_t)planes256[lane] + (uint64_t)m * (uint64_t)(1 + lane)) << 4) | (uint64_t)lane;
+    } else {
+        const int b = 29 - lane;
+        const uint64_t w = (lane < 30) ? ((uint64_t)planes256[b] << b) : 0ull;
+        const uint64_t tk = wave_scan_add_u64(w);  // lane l: T_(29-l)
+        if (lane >= 17 && lane < 30) key = (((tk >> b) + (uint64_t)m * (uint64_t)(1 + b)) << 4) | (uint64_t)b;
+    }
+    return (uint32_t)(wave_last_u64(wave_scan_min_u64(key)) & 15u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_analyze
+// ---------------------------------------------------------------------------------------------
+// The analysis of one slot (everything after the slot has been picked).
+template <class G>
+__device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const AnalyzeParams& prm, uint32_t n_in,
+                                             const SlotSrc& src, int64_t start, const LpcSet* __restrict__ lpc_slot,
+                                             ChannelPlan* __restrict__ plan_out, const int tid, const FuseArgs& fuse,
+                                             const long long fuse_idx, const bool fuse_flag_byte,
+                                             const uint32_t fuse_flag_value) {
+    Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
+    const uint32_t n = n_in;
+#ifdef LACX_STAMPS
+    unsigned long long stamp_acc[40];
+    for (int k = 0; k < 40; ++k) stamp_acc[k] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    Thread<G> th;
+    thread_init(th, n, tid);
+    stage_samples(th, sh, src, start);
+    for (int i = tid; i < (int)(sizeof(LpcSet) / 2); i += G::T)
+        reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(lpc_slot)[i];
+    if (tid < 32) {
+        sh.planeTot[0][tid] = sh.planeTot[1][tid] = 0;
+        sh.planeTot256[0][tid] = sh.planeTot256[1][tid] = 0;
+    }
+    if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
+    if (tid < 33) (&sh.lbacc[0][0])[tid] = 0;
+    if (tid < 2) sh.has4[tid] = 0;
+    if (tid == 0) sh.best_cand = -1;
+    __syncthreads();
+    STAMP(0);
+
+    // ---- pass 1: the pruning bound of every candidate ------------------------------------------------------------
+    // One walk over the chunk for all eleven candidates (pass1_bounds, analyze_core.h): window loaded once, nothing
+    // stored, no barrier between candidates (ref block/encoder.cpp:362-407 walks them one by one).  Per candidate the
+    // thread holds the sum of its leading-bit counts and a 2-bit code per position (zero / four / other) that is counted
+    // once per chunk.
+    {
+        // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
+        // addresses and masks derived from it and, at the 128-VGPR budget, spills them to scratch.
+        asm volatile("" : "+v"(th.a));
+        BoundPartials bp[11];
+        const bool lpc_off = (prm.debug_skip & 16u) != 0u;
+        if (n == (uint32_t)G::MAXN) pass1_bounds<G, true>(th, sh, lpc_off, bp);  // uniform
+        else pass1_bounds<G, false>(th, sh, lpc_off, bp);
+        // bit_width(u | 1) + 1 = 33 - clz(u | 1) = 34 - lead_m per position.  A zero counts 2 that way and is worth 1 (the
+        // wave's zero count takes the difference out); a position beyond the slot (r = 0) counts 2, is among those zeros
+        // and is worth nothing (the wave's `beyond` takes the rest out).
+        // Two candidates share a register for the wave sums (each sum stays below 2^16: 64 lanes x 34 x CH).
+        const uint32_t per_thread = 34u * (uint32_t)G::CH;
+        const int32_t left = (int32_t)n - (int32_t)((tid >> 6) * 64 * G::CH);  // samples of the slot from this wave's first one on
+        const uint32_t valid = left <= 0 ? 0u : (left >= 64 * G::CH ? (uint32_t)(64 * G::CH) : (uint32_t)left);
+        const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
+#pragma unroll
+        for (int c = 0; c < 12; c += 2) {
+            const uint32_t lo = per_thread - bp[c].msum, hi = c + 1 < 11 ? per_thread - bp[c + 1 < 11 ? c + 1 : c].msum : 0u;
+            const uint32_t g2 = wave_sum_u32(lo | (hi << 16));
+            const uint32_t cnt0 = wave_sum_u32(bound_counts<G::CH>(bp[c]));
+            const uint32_t cnt1 = c + 1 < 11 ? wave_sum_u32(bound_counts<G::CH>(bp[c + 1 < 11 ? c + 1 : c])) : 0u;
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int cc = c + h;
+                    if (cc < 11) {
+                        const uint32_t g = h ? (g2 >> 16) : (g2 & 0xFFFFu);
+                        const uint32_t cnt = h ? cnt1 : cnt0;
+                        const uint32_t nz = cnt & 0x7FFu, n4 = (cnt >> 11) & 0x7FFu, ends = cnt >> 22;
+                        atomicAdd(&sh.lbacc[cc][0], g - nz - beyond);
+                        atomicAdd(&sh.lbacc[cc][1], (nz - beyond) + (n4 << 16));
+                        atomicAdd(&sh.lbacc[cc][2], ends);
+                    }
+                }
+            }
+        }
+    }
+    STAMP(2);
+    __syncthreads();
+    if (tid <= 10) {
+        // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
+        const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || (prm.debug_skip & 16u))) ||
+                             (tid >= 1 && (prm.debug_skip & 64u)));
+        sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], sh.lbacc[tid][2], n, prm.zero_run) << 4) | (uint64_t)tid)
+                                 : ~0ull;
+    }
+    STAMP(5);
+
+    // ---- pass 2: exact costs, most promising candidate first ----------------------------------------------------------
+    // The reference keeps the first candidate with the strictly smallest cost = the minimum of (cost, index).  Candidates
+    // are evaluated in ascending (bound, index) order; one that cannot beat the best (cost, index) so far ends the search,
+    // because every remaining one has a bound at least as large (and, at an equal bound, a larger index).  A dismissed
+    // candidate costs nothing here: no residual, no barrier.
+    int pending = -1;        // candidate whose totals still have to be scored
+    uint32_t pending_k0 = 0;
+    bool pending_ksums = false;  // its totals are k-sums (32-bit blocks), not plane counts
+    uint32_t tried = 0;      // candidates already evaluated (uniform)
+    int parity = 0;
+    for (;;) {
+        if (tid < 64) {  // wave 0
+            if (pending >= 0) {
+                // previous candidate's totals sit in the other buffers: score it, then clear them
+                score_candidate_wave(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1], tid, pending_ksums);
+                if (tid < 32) sh.planeTot[parity ^ 1][tid] = sh.planeTot256[parity ^ 1][tid] = 0;
+                if (tid < 4) sh.acc[parity ^ 1][tid] = 0;
+            }
+            // next: the untried candidate with the smallest (bound, index), unless it cannot win any more
+            const uint64_t key = (tid <= 10 && !((tried >> tid) & 1u)) ? sh.cand_key[tid] : ~0ull;
+            const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
+            if (tid == 0) {
+                sh.has4[parity] = 0;
+                int next = best_key == ~0ull ? -1 : (int)(best_key & 15u);
+                if (next >= 0 && !(prm.debug_skip & 128u) && candidate_pruned(best_key >> 4, next, sh.best_bits, sh.best_cand)) next = -1;
+                sh.next_cand = next;
+            }
+        }
+        STAMP(1);
+        __syncthreads();  // Bsel: the previous candidate is scored, the next one chosen
+        STAMP(4);
+        const int cand = sh.next_cand;
+        if (cand < 0) break;  // uniform
+        tried |= 1u << cand;
+        asm volatile("" : "+v"(th.a));  // (see pass 1)
+        uint32_t* pt = sh.planeTot[parity];
+        uint32_t* pt256 = sh.planeTot256[parity];
+        unsigned long long* acc = sh.acc[parity];
+        {
+            uint32_t ures[G::CH];
+            phase_r_residual(th, sh, cand, ures);
+            phase_r_store(th, sh, ures);
+        }
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        STAMP(3);
+        __syncthreads();  // B1b: the wave totals of the scan
+        const uint64_t total_u = scan_pz_part2(sh, tid, sr);
+        const bool narrow = total_u < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
+        const bool ksums = narrow && !(prm.debug_skip & 262144u);
+        if (!(prm.debug_skip & 1u)) {
+            if (ksums) ksums_wave(th, pt, pt256, tid); else plane_totals_wave(th, pt, pt256, tid);
+        }
+        // the first 256 samples all belong to wave 0: its own totals are complete once its atomics are (same wave,
+        // program order), so it can derive the initial k at once; every other thread reads it after B3
+        if (tid < 64) {
+            const uint32_t k0w = initial_k_wave(pt256, n, tid, ksums);
+            if (tid == 0) sh.cur_k0 = k0w;
+        }
+        STAMP(6);
+        if (prm.debug_skip & 2u) {
+            sh.tabF[tid] = 0;
+            th.has4 = 1u;
+        } else if (narrow) {
+            phase_a<G, true>(th, sh);
+        } else {
+            phase_a<G, false>(th, sh);
+        }
+        if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B3
+        STAMP(8);
+        __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own), prefixes in tabP
+        STAMP(10);
+        const uint32_t k0 = sh.cur_k0;
+        if (prm.debug_skip & 4u) {
+            th.crice = th.cbin = th.czr = 1;
+            th.chasrun = 0;
+        } else {
+            // the zero-run cost only matters when the residual has a run of >= 4 zeros somewhere
+            const bool zr = prm.zero_run && sh.has4[parity] != 0u;
+            phase_b_dispatch<G>(th, sh, k0, narrow, zr, n == (uint32_t)G::MAXN);
+        }
+        STAMP(12);
+        {
+            const bool active = (uint32_t)th.a < n;
+            const uint64_t r0 = wave_sum_u64(active ? th.crice : 0ull);
+            const uint64_t r1 = wave_sum_u64(active ? th.cbin : 0ull);
+            const uint64_t r2 = wave_sum_u64(active ? th.czr : 0ull);
+            const uint32_t r3 = wave_or_u32(active ? th.chasrun : 0u);
+            if ((tid & 63) == 0) {
+                atomicAdd(&acc[0], (unsigned long long)r0);
+                atomicAdd(&acc[1], (unsigned long long)r1);
+                atomicAdd(&acc[2], (unsigned long long)r2);
+                atomicAdd(&acc[3], (unsigned long long)r3);
+            }
+        }
+        STAMP(13);
+        __syncthreads();  // B5
+        STAMP(14);
+        pending = cand;
+        pending_k0 = k0;
+        pending_ksums = ksums;
+        parity ^= 1;
+    }
+
+    STAMP(15);
+    // ---- partition search on the winning residual -------------------------------------------
+    const int best = sh.best_cand;
+    int max_p = 0;
+    if (prm.partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
+    const int nseg = max_p > 0 ? ((2 << max_p) - 2) : 0;
+    PartMem<G>& pm = sh.xp.part;
+    auto clear_partition_scratch = [&]() {  // aliases the staged samples: only once every thread is done with them
+        for (int i = tid; i < nseg; i += G::T) {
+            pm.segacc[i][0] = pm.segacc[i][1] = pm.segacc[i][2] = 0;
+            pm.segrun[i] = 0;
+        }
+        if (tid <= G::MAXP) pm.pbits[tid] = 0;
+    };
+    if (best == pending && !(prm.debug_skip & 16384u)) {
+        // The winner is the candidate evaluated last (usually the only one): its residual is still in sh.u, with the
+        // micro-window flags of phase A in bits 30/31, its prefix sums in tabP / tabNZ, its plane counts in th.cs.
+        // Strip the flags; nobody reads the staged samples any more (the last barrier of the search is behind us).
+#pragma unroll
+        for (int i = 0; i < G::CH; ++i) sh.u[i * G::T + tid] &= 0x3FFFFFFFu;
+        clear_partition_scratch();
+        __syncthreads();
+    } else {
+        phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
+        ScanRegs<G> sr;
+        scan_pz_part1(sh, tid, sr);
+        __syncthreads();
+        clear_partition_scratch();
+        scan_pz_part2(sh, tid, sr);
+        __syncthreads();
+    }
+    const bool pnarrow = sh.tabP[G::T] < (1ull << 31);
+    STAMP(16);
+    if (max_p > 0) {
+        {
+            // the TPG neighbouring lanes of a 64-sample group own its table entry: sum them on the DPP network, one plain
+            // store by the group's last lane (no atomics; the entries need no clearing)
+            constexpr int kLog = G::TPG == 4 ? 2 : 4;
+            static_assert(G::TPG == 4 || G::TPG == 16, "lanes per 64-sample group");
+            uint32_t words[15];
+            packed_planes(th, words);
+            const bool last = (tid & (G::TPG - 1)) == G::TPG - 1;
+#pragma unroll
+            for (int w = 0; w < 15; ++w) {
+                const uint32_t v = seg_sum_u32<kLog>(words[w]);
+                if (last) pm.grp[w][tid / G::TPG] = v;
+            }
+            if (tid < 15) pm.grp[tid][G::NG] = 0;  // the slot past the last group (the scan's total)
+        }
+        __syncthreads();
+        {
+            constexpr int NW = G::T / 64;
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(pm.grp[w], G::NG + 1, lane);
+        }
+        __syncthreads();
+        STAMP(17);
+        for (int idx = tid; idx < ((prm.debug_skip & 32u) ? 0 : nseg); idx += G::T) {
+            const int p = 31 - __clz(idx + 2);
+            seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
+        }
+        __syncthreads();
+        STAMP(18);
+        auto flush = [&pm](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
+                           uint32_t hr) {
+            atomicAdd(&pm.segacc[idx][0], rc);
+            atomicAdd(&pm.segacc[idx][1], bn);
+            atomicAdd(&pm.segacc[idx][2], zr);
+            if (hr) atomicOr(&pm.segrun[idx], 1u);
+        };
+        if (prm.debug_skip & 8u) {
+            // (timing ablation only)
+        } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
+            // all orders in one walk (every full block, every probe); without a run of >= 4 zeros in the
+            // block no partition can have one, so the zero-run costs are not needed.  Narrow sums: every segment total
+            // stays below 2^32 (sum of u < 2^31, at most 35 bits of overhead per sample), so 32-bit LDS atomics on the
+            // low words of the (zeroed) 64-bit accumulators suffice.
+            // One atomic per accumulator and segment of neighbouring lanes (see seg_sum_u32): the lanes of a partition of
+            // order p are (n >> p) / CH neighbours -- a power of two for every full block and every probe; other sizes
+            // fall back to one atomic per lane.  Called by every lane of the wave (idle lanes pass zeros).
+            const bool ablate_flush = (prm.debug_skip & 65536u) != 0u;
+            const uint32_t chunks = n / (uint32_t)G::CH;  // chunks of the slot
+            const bool pow2 = (chunks & (chunks - 1u)) == 0u && !(prm.debug_skip & 131072u);
+            auto seg_flush = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr, bool with_zr) {
+                if (ablate_flush) return;
+                const uint32_t lanes = chunks >> (q + 1);  // lanes per partition of this order (wave-uniform)
+                if (pow2 && lanes >= 2u) {
+                    const int lg = lanes >= 64u ? 6 : 31 - __clz((int)lanes);
+                    const bool last = ((uint32_t)tid & ((1u << lg) - 1u)) == (1u << lg) - 1u;
+                    rc = seg_sum_u32(rc, lg);
+                    bn = seg_sum_u32(bn, lg);
+                    if (with_zr) zr = seg_sum_u32(zr, lg);
+                    if (last) {
+                        atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                        atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                        if (with_zr) atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                    }
+                } else {
+                    atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                    atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                    if (with_zr) atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                }
+                if (hr) atomicOr(&pm.segrun[idx], 1u);
+            };
+            auto flush32 = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr) {
+                seg_flush(q, idx, rc, bn, zr, hr, true);
+            };
+            auto flush32_nozr = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+                seg_flush(q, idx, rc, bn, 0u, 0u, false);
+            };
+            // (one queued chunk of partition_quick: any partition, any order per lane)
+            auto flush_entry = [&pm, ablate_flush](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+                if (ablate_flush) return;
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
+                atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+            };
+            if (prm.zero_run && sh.best_hasrun) {
+                partition_fused<G, true>(th, sh, max_p, flush32);
+            } else if (prm.debug_skip & 32768u) {
+                partition_fused<G, false>(th, sh, max_p, flush32_nozr);  // (A/B: the plain walk)
+            } else {
+                // no sample walk where the Rice parameter is provably constant over the chunk; the other (chunk, order)
+                // pairs are queued and walked densely packed
+                // (per wave: no workgroup barrier, no atomic -- a wave's queue is filled and drained by the wave itself)
+                uint16_t* wq = &pm.queue[(tid >> 6) * 64 * G::MAXP];
+                uint32_t queued = 0;  // wave-uniform
+                partition_quick<G>(th, sh, max_p, flush32_nozr, [&](uint32_t entry, bool ambiguous) {
+                    const unsigned long long m = __ballot(ambiguous);
+                    if (ambiguous) wq[queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)entry;
+                    queued += (uint32_t)__popcll(m);
+                });
+                STAMP(7);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS stores, before it reads them back
+                for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) partition_slow_entry<G>(sh, n, wq[e], flush_entry);
+                STAMP(9);
+            }
+        } else {
+            for (int p = 1; p <= max_p; ++p) {
+                if (pnarrow) {
+                    partition_pass<G, true>(th, sh, p, flush);
+                } else {
+                    partition_pass<G, false>(th, sh, p, flush);
+                }
+            }
+        }
+        STAMP(19);
+        __syncthreads();
+        STAMP(20);
+        // Segment idx of order p has idx + 2 in [2^p, 2^(p+1)): walking j = idx + 2 in chunks of 64 gives every wave
+        // from j = 64 on segments of ONE order -- one atomic per wave there instead of 64 on one address.
+        for (int j0 = tid & ~63; j0 < nseg + 2; j0 += G::T) {  // wave-uniform trip count
+            const int j = j0 + (tid & 63), idx = j - 2;
+            const bool valid = j >= 2 && idx < nseg;
+            const unsigned long long bits = valid ? seg_choose(sh, (uint32_t)idx, prm.zero_run) : 0ull;
+            if (j0 >= 64) {
+                const unsigned long long sum = wave_sum_u64(bits);
+                if ((tid & 63) == 0) atomicAdd(&pm.pbits[31 - __clz(j0)], sum);
+            } else if (valid) {
+                atomicAdd(&pm.pbits[31 - __clz(j)], bits);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &sh.plan);
+    __syncthreads();
+    // only the head and the partitions in use: the rest of the record is zero already (the plans are cleared per call)
+    const int plan_words = (int)(offsetof(ChannelPlan, part_mode_k) + ((size_t)1 << sh.plan.partition_order) + 3) / 4;
+    for (int i = tid; i < plan_words; i += G::T)
+        reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
+    STAMP(21);
+    if constexpr (G::T == 1024) {
+        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid STAMP_ARGS);  // uniform
+    }
+    STAMP(23);
+#if defined(LACX_STAMPS) && LACX_STAMPS == 1
+    // one wave per workgroup reports (a different one from workgroup to workgroup): with every wave adding its 24
+    // sums to the same addresses the atomics themselves slowed every global load in the kernel down severalfold
+    if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u) && G::T == 1024) {
+        stamp_acc[22] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+        for (int k = 0; k < 32; ++k) atomicAdd(&g_stamp_acc[k], stamp_acc[k]);
+        atomicAdd(&g_stamp_acc[32], 1ull);
+    }
+#endif
+}
+
+// (At 127 VGPRs x 4 waves per SIMD an analysis workgroup fills the register files of its CU, so every workgroup of the
+// streaming packer takes a whole CU away from the analysis: measured +25 us of kernel time per packer workgroup, hence
+// the packer's small grid.  The compiler offers no way to cap this kernel at 120.)
+template <class G>
+__global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
+                                                  int which_base, const LpcSet* __restrict__ lpcs,
+                                                  const uint32_t* __restrict__ need,
+                                                  ChannelPlan* __restrict__ plans,
+                                                  unsigned long long* __restrict__ t_first,
+                                                  unsigned long long* __restrict__ t_last, FuseArgs fuse) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
+    if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
+    // should be one that has work.  Whole-block class: the stream's workgroup w analyses the (w % per)-th needed slot of
+    // its block w / per (per = the stream's channels; the streams of a set follow each other in the grid).  Probe class:
+    // 12 slots per block, skipped unless the block is uncertain.  which_base != 0: the two extra workgroups of ONE block
+    // (global block one_block) whose four channels are all needed.
+    uint32_t blk;  // global block of the launch set
+    int slot = -1;
+    int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
+    uint32_t needed_slots = 0;
+    StreamDesc sd;
+    if (probe_class) {
+        blk = blockIdx.x / 12u;
+        sd = stream_of_block_uniform(br, blk);
+        const int s = 4 + (int)(blockIdx.x % 12u);
+        if ((need[blk] >> s) & 1u) slot = s;
+    } else {
+        uint32_t wsel;
+        if (which_base) {
+            blk = one_block;
+            sd = stream_of_block_uniform(br, blk);
+            wsel = blockIdx.x;
+        } else {
+            sd = stream_of_workgroup(br, blockIdx.x);
+            const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
+            uint32_t lblk;
+            xcd_slot(blockIdx.x - sd.first_wg, per, (sd.prm.debug_skip & 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
+            blk = sd.first_block + lblk;
+        }
+        int which = (int)wsel + which_base;
+        which_in_block = which;
+        uint32_t m = need[blk] & 0xFu;
+        needed_slots = (uint32_t)__popc(m);
+        while (m) {
+            const int s = __ffs((int)m) - 1;
+            if (which == 0) {
+                slot = s;
+                break;
+            }
+            --which;
+            m &= m - 1u;
+        }
+    }
+    if (slot < 0) return;  // uniform for the workgroup
+    const AnalyzeParams prm = sd.prm;
+    const uint32_t lblk = blk - sd.first_block;
+    const SlotGeom g = slot_geom(prm, lblk, slot);
+    const uint32_t n = g.n;
+    const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
+    const SlotSrc src = slot_src(prm, sd.left, sd.right, slot & 3);
+
+    // Fused emit: only where the block's channel pair is already final, i.e. exactly `channels` whole-block slots are
+    // needed (a small final block that is encoded both ways and compared afterwards is left to k_emit).
+    long long fuse_idx = -1;
+    bool flag_byte = false;
+    if (fuse.slots && !probe_class && !which_base) {
+        const uint32_t item = lblk * (uint32_t)prm.channels + (uint32_t)which_in_block;  // within the stream
+        fuse_idx = (long long)prm.stream_base + item;
+        flag_byte = prm.channels == 2 && prm.stereo_mode == 2 && which_in_block == 0;
+        // the host excludes a small final block that may be encoded both ways and compared afterwards (fuse_items)
+        if (item >= sd.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
+    }
+    analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid, fuse, fuse_idx, flag_byte,
+                    (uint32_t)((slot & 3) >= 2 ? 1u : 0u));
+    if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+size_t analyze_smem_bytes_full() { return sizeof(Smem<GFull>); }
+
+int debug_read_stamps(unsigned long long* out32) {
+#ifdef LACX_STAMPS
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * 40) != hipSuccess) return 0;
+    unsigned long long zero[40] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof(zero));
+    return 1;
+#else
+    (void)out32;
+    return 0;
+#endif
+}
+size_t analyze_smem_bytes_probe() { return sizeof(Smem<GProbe>); }
+
+// The opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) applies to the device
+// that is current when it is set, and one process may drive several devices (one encoder per lacx_config.device):
+// the state is kept per device ordinal, under a mutex (first launches of two encoders may come from two host
+// threads), and only successes are remembered -- a transient failure is retried by the next call.
+hipError_t ensure_kernel_attrs() {
+    static std::mutex mu;
+    static bool done[kMaxDevices] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GFull>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GFull>));
+    if (e == hipSuccess) e = set_kernel_attrs_front();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
+    if (e == hipSuccess) e = set_kernel_attrs_emit();
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
+hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
+                           const FuseArgs* fuse, hipEvent_t wait_before_full) {
+    const FuseArgs fa = fuse ? *fuse : FuseArgs{};
+    hipError_t e = ensure_kernel_attrs();
+    if (e != hipSuccess) return e;
+    const BatchRef& br = ls.br;
+    const uint32_t nb = br.total_blocks;
+    if (nb == 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, br, ws.sums, ws.badidx, ws.acorr);
+    hipLaunchKernelGGL(k_stereo, dim3((nb + 3) / 4), dim3(64), 0, stream, br, ws.sums, ws.badidx, ws.bplans,
+                       ws.need_probe, ws.need_full);
+    hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
+                       sizeof(LevMem), stream, br, ws.acorr, ws.need_probe, ws.lpcs);
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    // per-block stereo in any stream of the set: probes + decision; a final block of <= 4096 frames of such a stream can
+    // need all four channels (full LR-vs-MS comparison, ref lac/encoder.cpp:336-340)
+    bool any_auto = false, any_both = false;
+    uint32_t total_wg = 0;
+    for (uint32_t i = 0; i < ls.nstreams; ++i) {
+        const AnalyzeParams& p = ls.streams[i].prm;
+        const bool autost = p.channels == 2 && p.stereo_mode == 2;
+        any_auto = any_auto || autost;
+        any_both = any_both || (autost && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit);
+        total_wg += p.num_blocks * (p.channels == 2 ? 2u : 1u);
+    }
+    if (any_auto) {
+        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, br, 1, 0u, 0,
+                           ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
+                           ws.need_full, ws.plans);
+    }
+    if (ev) (void)hipEventRecord(ev[2], stream);
+    if (wait_before_full) {
+        const hipError_t we = hipStreamWaitEvent(stream, wait_before_full, 0);
+        if (we != hipSuccess) return we;
+    }
+    hipLaunchKernelGGL(k_analyze<GFull>, dim3(total_wg), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
+                       ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa);
+    if (any_both) {  // the 3rd and 4th slots of such a final block: a two-workgroup launch each
+        for (uint32_t i = 0; i < ls.nstreams; ++i) {
+            const StreamDesc& sd = ls.streams[i];
+            const AnalyzeParams& p = sd.prm;
+            if (p.channels == 2 && p.stereo_mode == 2 && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit)
+                hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0,
+                                   sd.first_block + p.num_blocks - 1u, 2, ws.lpcs, ws.need_full, ws.plans,
+                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+        }
+    }
+    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (any_both) {  // phase 2 only concerns such final blocks
+        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 2, ws.bplans, ws.need_probe,
+                           ws.need_full, ws.plans);
+    }
+    if (ev) (void)hipEventRecord(ev[4], stream);
+    return hipGetLastError();
+}
+
+}  // namespace lacx

@@ -1,4 +1,5 @@
-// kernels.h -- host-visible interface of kernels.hip.
+// kernels.h -- host-visible interface of the kernel translation units (k_front.hip, k_analyze.hip, k_emit.hip,
+// decode.hip, wide.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -30,7 +31,7 @@ struct DeviceWorkspace {
     unsigned long long slot_stride = 0;
     uint32_t* emitted = nullptr;              // 2: the analysis kernel put the bitstream into the slot
     uint32_t* packed = nullptr;               // 1: the streaming packer moved it to the payload
-    unsigned long long* size_rec = nullptr;   // hand-off words of the fused emit (see kernels.hip)
+    unsigned long long* size_rec = nullptr;   // hand-off words of the fused emit (see k_analyze.hip)
     unsigned long long* ready_rec = nullptr;
     unsigned long long* stream_pre = nullptr; // [streams] k_offsets: payload prefix at every stream's first block (sets of several streams)
 };

@@ -1,6 +1,6 @@
 // wide.hip -- Block::Encoder::encode for blocks outside the 25-bit domain of the streaming kernels.
 //
-// LAC::Encoder validates its input to 16 / 24 bits, so the kernels of kernels.hip only ever see |x| <= 2^24 (mid/side
+// LAC::Encoder validates its input to 16 / 24 bits, so the streaming kernels (k_front / k_analyze / k_emit) only ever see |x| <= 2^24 (mid/side
 // included): residuals below 2^30, 32-bit fast paths, two flag bits inside the residual words.  Block::Encoder itself
 // has no such limit (ref src/codec/block/encoder.cpp:313-316 takes any int32 samples and never throws): there the LPC
 // residual can leave int32 and the encoder falls back to the next lower order of {12, 10, 8, 6, 4}, finally to order 0

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Kernel resource usage (VGPRs, SGPRs, scratch, LDS, occupancy) of csrc/kernels.hip as hipcc reports it.
+# Kernel resource usage (VGPRs, SGPRs, scratch, LDS, occupancy) of the kernel units (k_front, k_analyze, k_emit, decode, wide) as hipcc reports it.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-hipcc -O3 -std=c++17 --offload-arch=gfx950 $EXTRA -I$ROOT/lossless-audio-codec_amd/csrc -I$ROOT/include -c $ROOT/lossless-audio-codec_amd/csrc/kernels.hip \
-  -Rpass-analysis=kernel-resource-usage -o /tmp/kres.o 2>&1 | python3 -c '
+for u in k_front k_analyze k_emit decode wide; do
+hipcc -O3 -std=c++20 --offload-arch=gfx950 $EXTRA -I$ROOT/lossless-audio-codec_amd/csrc -I$ROOT/include -c $ROOT/lossless-audio-codec_amd/csrc/$u.hip \
+  -Rpass-analysis=kernel-resource-usage -o /tmp/kres.o 2>&1
+done | python3 -c '
 import sys, re
 cur = None
 for line in sys.stdin:
