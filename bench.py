@@ -163,6 +163,9 @@ def worker(args) -> int:
 
     # cores this process may run on (the box confines a one-GPU lease to its CPU share), not the host's total
     host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()  # a CPU-time quota (cgroup cpu.max) confines the lease where the affinity mask does not
+    if quota is not None:
+        host_cores = max(1, min(host_cores, quota))
     host_cores_total = os.cpu_count() or host_cores
     # host threads of this rank: the box's CPU share per GPU (16), overridable for tuning
     share = max(1, host_cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
@@ -544,7 +547,7 @@ def worker(args) -> int:
         main["left"] = main["right"] = None
         other = []
 
-        def timed_job(name, specs, steps=5, warmup=1):
+        def timed_job(name, specs, steps=8, warmup=2):
             # specs: (digest name, frames, channels, bit_depth, rate, stereo_mode, kind, stereo family, seed)
             jobs = []
             for dname, frames_j, ch, bd, sr, sm, kind, st, seed in specs:
@@ -561,8 +564,11 @@ def worker(args) -> int:
                 run()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            each = []
             for _ in range(steps):
+                t2 = time.perf_counter()
                 res, kernel_ms = run()
+                each.append(round((time.perf_counter() - t2) * 1e3, 3))
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / steps
             ok = True
@@ -574,7 +580,7 @@ def worker(args) -> int:
                 raise SystemExit(f"bench.py: {name}: a .lac does not match the reference's golden digest -- refusing to report a number")
             other.append({"workload": name, "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
                           "ms_per_step": round(dt * 1e3, 3), "kernel_ms": round(kernel_ms, 3), "streams": len(jobs),
-                          "samples": samples, "steps": steps, "matches_golden_digest": True})
+                          "samples": samples, "steps": steps, "ms_each_step": each, "matches_golden_digest": True})
             del jobs
 
         def make_runner(jobs):
@@ -664,6 +670,26 @@ def worker(args) -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def cgroup_cpu_quota():
+    """Whole cores of CPU time this process's cgroup may use (v2 cpu.max, v1 cfs quota), or None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return -(-int(q) // int(per))
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return -(-q // per) if q > 0 and per > 0 else None
+    except (OSError, ValueError):
+        return None
 
 
 def main():

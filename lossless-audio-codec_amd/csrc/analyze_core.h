@@ -129,6 +129,7 @@ LACX_HD uint32_t kmean(uint64_t S, uint32_t c) {
     return (X < 2ull * c) ? 0u : k;
 }
 // same, for S + (c>>1) < 2^32
+// (k <= 30 whatever the sums are: the mean never exceeds the largest u, and u < 2^30)
 LACX_HD uint32_t kmean32(uint32_t S, uint32_t c) {
     const uint32_t X = S + (c >> 1);
     const uint32_t Y = X - c;
@@ -136,6 +137,11 @@ LACX_HD uint32_t kmean32(uint32_t S, uint32_t c) {
     const uint32_t k = (uint32_t)g + ((Y >> (g & 31)) >= c ? 1u : 0u);
     return (X < 2u * c) ? 0u : k;
 }
+
+// A block (a candidate's residual) is "narrow" when its sum of u stays below this: every prefix sum, every sum plus half a
+// count, and every cost total of a partition (at most 36 bits of overhead per sample on top of u: 16384 x 36 < 2^20)
+// then fits 32 bits -- all but the loudest 24-bit material.
+constexpr uint64_t kNarrowLimit = (1ull << 32) - (1ull << 20);
 
 template <bool NARROW>
 LACX_HD uint32_t kmean_t(uint64_t S, uint32_t c) {
@@ -235,6 +241,9 @@ struct Smem {
     uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
     uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
+    uint16_t tabZM[G::T];     // phase A: bit i = sample i of the chunk has the "zero quotient" micro flag (phase_b_quick)
+    uint16_t bqueue[G::T];    // chunks whose adaptive costs need the walk (phase B), packed over the lanes of the waves
+    uint32_t bqcount;
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
     uint32_t planeTot256[2][32]; // ... over the first min(256,n) samples
     unsigned long long acc[2][4];  // rice, bin, zr bits and has_run of the current candidate
@@ -272,6 +281,7 @@ struct Thread {
     unsigned long long crice, cbin, czr;  // chunk partial costs
     uint32_t chasrun;
     uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
+    uint32_t umin;    // phase A: smallest u of the chunk
 };
 
 template <class G>
@@ -772,8 +782,11 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
     uint32_t cnt = 0;
     uint32_t c = (uint32_t)th.a;
     uint32_t zm = 0;  // bit i: sample i of the chunk is zero
+    uint32_t mn = 0xFFFFFFFFu;
+    uint32_t fzm = 0;  // bit i: sample i has the zero-quotient flag
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t u = sh.u[i * G::T + th.tid];
+        mn = u < mn ? u : mn;
         P += u;
         ++c;
         const uint32_t km = kmean_t<NARROW>(P, c);
@@ -782,8 +795,11 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
         sh.u[i * G::T + th.tid] = u | (fl << 30) | (fz << 31);
         cnt += fl + (fz << 16);
         zm |= (u == 0u ? 1u : 0u) << i;
+        fzm |= fz << i;
     }
     sh.tabF[th.tid] = cnt;
+    if constexpr (requires { sh.tabZM[0]; }) sh.tabZM[th.tid] = (uint16_t)fzm;
+    th.umin = mn;
     // Zero-run mode can only matter when some run of >= 4 zeros exists (ref block/encoder.cpp:224-247 sets
     // has_run only then).  Such a run lies inside one chunk, or crosses into a chunk: then the zeros ending
     // just before the chunk plus the chunk's leading zeros reach 4.
@@ -812,14 +828,22 @@ LACX_HD uint32_t window_flags(const uint32_t* tabF, int t) {
 }
 
 // Phase B (stateful, whole block as one segment): rice/bin/zero-run bit costs
-// (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114).
-// FULL: every chunk of the slot is complete (n == MAXN, block-uniform): a fixed trip count, no per-lane loop exit.
-// STEADY: the chunk starts at sample 256 or later (wave-uniform: every wave but the first of a 1024-thread slot): the
-// window taps exist and the count thresholds of the bias are met throughout.
-template <class G, bool NARROW, bool ZR = true, bool FULL = false, bool STEADY = false>
-LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
-    const int t = th.tid;
-    const uint32_t n = th.n;
+// (ref block/encoder.cpp:201-263 with Rice::adapt_k, rice.hpp:45-114) of samples [i0, i1) of chunk t.
+// The parameter in force for a sample is a function of running sums only (prefix sum, count, the sum of the last 256,
+// the flag counts of the last 96), never of the parameter before it: a span can start anywhere in the chunk once those
+// sums have been carried over the samples it skips (a few adds each).  (Sharing the walk of a chunk out over four lanes
+// that way was measured and lost to walking whole chunks: the carry-over and the set-up outweigh the shorter chain.)
+// TRIPS > 0: i1 - i0 == TRIPS for every lane (a fixed trip count, no per-lane loop exit).
+// STEADY: the chunk starts at sample 1024 or later (every wave but the first of a 1024-thread slot): the window taps
+// exist and the count thresholds of the bias are met throughout.
+struct ChunkCosts {
+    unsigned long long rice, bin, zr;
+    uint32_t hasrun;
+};
+
+template <class G, bool NARROW, bool ZR = true, int TRIPS = 0, bool STEADY = false>
+LACX_HD ChunkCosts phase_b_span(const Smem<G>& sh, uint32_t n, int t, int i0, int i1, uint32_t k0) {
+    const int a = t * G::CH;
     uint64_t P = sh.tabP[t];                                   // P_{a-1}
     uint64_t W = (STEADY || t >= G::W256) ? sh.tabP[t - (STEADY || t >= G::W256 ? G::W256 : 0)] : 0;    // P_{a-1-256}
     // packed flag counts over the 96 samples before the chunk = its W96 predecessors' chunk counts (the window
@@ -829,27 +853,39 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
     const uint32_t m96 = (STEADY || t >= G::W96) ? 0xFFFFFFFFu : 0u;
     const int t256 = (STEADY || t >= G::W256) ? t - G::W256 : t;
     const int t96 = (STEADY || t >= G::W96) ? t - G::W96 : t;
-    uint32_t c = (uint32_t)th.a;
-    // k in force for the first sample of the chunk: the value returned after sample a-1
+    uint32_t c = (uint32_t)a;
+    int32_t f = a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
+    // carry the sums over the samples before the span (none when the span opens the chunk)
+    for (int j = 0; j < i0; ++j) {
+        const uint32_t w = sh.u[j * G::T + t], w96 = sh.u[j * G::T + t96] & m96;
+        const uint32_t u = w & 0x3FFFFFFFu;
+        P += u;
+        ++c;
+        W += sh.u[j * G::T + t256] & m256;
+        D += ((w >> 30) & 1u) + ((w >> 31) << 16);
+        D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
+        f = (f + 1) & (int32_t)(0u - flag01(u == 0u));
+    }
+    // k in force for the first sample of the span: the value returned after the sample before it
     uint32_t kin = k0;
-    if (STEADY || (th.a > 0 && th.cnt > 0)) kin = biased_k<NARROW, STEADY>(kmean_t<NARROW>(P, c), P, W, D, c);
-    int32_t f = th.a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
-    // chunk sums: 32 bits suffice on the narrow path (each cost <= u + 34 and the block's sum of u is < 2^31)
+    if (STEADY || (c > 0u && i1 > i0)) kin = biased_k<NARROW, STEADY>(kmean_t<NARROW>(P, c), P, W, D, c);
+    // span sums: 32 bits suffice on the narrow path (each cost <= u + 36 and the block's sum of u is below kNarrowLimit)
     using Acc = typename std::conditional<NARROW, uint32_t, unsigned long long>::type;
     Acc rice = 0, bin = 0, zr = 0;
     uint32_t hasrun = 0;
-    uint32_t w0 = sh.u[t];  // own sample incl. flags
+    const int ifirst = i0 & (G::CH - 1);
+    uint32_t w0 = sh.u[ifirst * G::T + t];  // own sample incl. flags
     uint32_t n1 = 1, n2 = 1, n3 = 1;
     if (ZR) {
-        n1 = peek_u<G>(sh, (uint32_t)th.a + 1u, n);
-        n2 = peek_u<G>(sh, (uint32_t)th.a + 2u, n);
-        n3 = peek_u<G>(sh, (uint32_t)th.a + 3u, n);
+        n1 = peek_u<G>(sh, (uint32_t)(a + i0) + 1u, n);
+        n2 = peek_u<G>(sh, (uint32_t)(a + i0) + 2u, n);
+        n3 = peek_u<G>(sh, (uint32_t)(a + i0) + 3u, n);
     }
-    const int trips = FULL ? G::CH : th.cnt;
     // the window taps of the current trip are fetched one trip ahead (their latency hides behind the trip's arithmetic)
-    uint32_t tap256 = sh.u[t256], tap96 = sh.u[t96];
+    uint32_t tap256 = sh.u[ifirst * G::T + t256], tap96 = sh.u[ifirst * G::T + t96];
+    const int last = TRIPS > 0 ? i0 + TRIPS : i1;
 #pragma nounroll  // one sample per trip: the 16-fold body does not fit the register budget
-    for (int i = 0; i < trips; ++i) {
+    for (int i = i0; i < last; ++i) {
         const uint32_t cur256 = tap256, cur96 = tap96;
         const int inext = (i + 1) & (G::CH - 1);
         const uint32_t wnext = sh.u[inext * G::T + t];
@@ -884,20 +920,31 @@ LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
         if (ZR) {
             n1 = n2;
             n2 = n3;
-            n3 = peek_u<G>(sh, (uint32_t)(th.a + i) + 4u, n);
+            n3 = peek_u<G>(sh, (uint32_t)(a + i) + 4u, n);
         }
     }
-    th.crice = rice;
-    th.cbin = bin;
-    th.czr = zr;
-    th.chasrun = hasrun;
+    ChunkCosts out;
+    out.rice = rice;
+    out.bin = bin;
+    out.zr = zr;
+    out.hasrun = hasrun;
+    return out;
+}
+
+// The whole chunk of the thread.  FULL: every chunk of the slot is complete (n == MAXN, block-uniform).
+template <class G, bool NARROW, bool ZR = true, bool FULL = false, bool STEADY = false>
+LACX_HD void phase_b(Thread<G>& th, const Smem<G>& sh, uint32_t k0) {
+    const ChunkCosts cc = phase_b_span<G, NARROW, ZR, FULL ? G::CH : 0, STEADY>(sh, th.n, th.tid, 0, th.cnt, k0);
+    th.crice = cc.rice;
+    th.cbin = cc.bin;
+    th.czr = cc.zr;
+    th.chasrun = cc.hasrun;
 }
 
 // Picks the instance of phase_b: narrow / zr / full are block-uniform; the chunk-position instance (STEADY) is taken by
 // every wave but the first of a multi-wave slot (a >= 64 * CH >= 256, wave-uniform).
 template <class G>
-LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, bool narrow, bool zr, bool full) {
-    const bool steady = G::T > 64 && th.tid >= 64 && 64 * G::CH >= 256;
+LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, bool narrow, bool zr, bool full, bool steady) {
     auto go = [&](auto narrow_t, auto zr_t) {
         constexpr bool N = decltype(narrow_t)::value, Z = decltype(zr_t)::value;
         if (full) {
@@ -911,6 +958,111 @@ LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, boo
     } else {
         if (zr) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{});
     }
+}
+template <class G>
+LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, bool narrow, bool zr, bool full) {
+    phase_b_dispatch<G>(th, sh, k0, narrow, zr, full, G::T > 64 && th.tid >= 64 && 64 * G::CH >= 256);
+}
+
+// The walk of chunk t (t >= 64: the steady instance) by whichever lane the queue of phase B hands it to; the chunk's
+// costs are added to the lane's own.
+template <class G>
+LACX_HD void phase_b_queued(Thread<G>& th, const Smem<G>& sh, int t, uint32_t k0, bool narrow, bool zr, bool full) {
+    Thread<G> c;
+    thread_init(c, th.n, t);
+    phase_b_dispatch<G>(c, sh, k0, narrow, zr, full, true);
+    th.crice += c.crice;
+    th.cbin += c.cbin;
+    th.czr += c.czr;
+    th.chasrun |= c.chasrun;
+}
+
+// Phase B of one chunk without the walk, where that is provably the same thing.  The Rice parameter in force for a sample
+// is a function of four running quantities (ref rice.hpp:68-113): the prefix sum P and count c (unbiased k), the sum of
+// the last 256 (drift) and the flag counts of the last 96 (micro window).  Over the CH samples of a chunk each of them
+// moves inside an interval known from the tables the block scans have already built -- P in [tabP[t], tabP[t+1]], the
+// sum leaving the 256-window in chunk t - W256's sum, the flags entering / leaving the 96-window in tabF[t] /
+// tabF[t - W96] (the zero flags sample by sample, from tabZM) -- and every comparison of adapt_k is monotone in them.  When all of them come out the same at both ends
+// of the intervals the parameter is one constant k for the whole chunk, and with no sample <= 4 (no zero, no short bin
+// code) and none above the zero-run escape the three adaptive costs are the chunk's k-sum from its plane counts:
+//   rice = sum (u >> k) + CH (1 + k),  bin = zero-run = rice + 2 CH.
+// Returns false (costs untouched) when any of this cannot be shown; the caller then walks the chunk (phase_b).
+// Needs the full windows behind the chunk (every wave but the first of a whole-block slot) and a complete chunk.
+template <class G, bool NARROW, bool ZR>
+LACX_HD bool phase_b_quick(Thread<G>& th, const Smem<G>& sh) {
+    if constexpr (G::T <= 64 || 64 * G::CH <= 256) {
+        return false;
+    } else {
+        const int t = th.tid;
+        if (t < 64 || th.cnt != G::CH) return false;  // c > 256 throughout (the drift is armed), all window taps exist
+        using Sum = typename std::conditional<NARROW, uint32_t, uint64_t>::type;
+        const Sum P0 = (Sum)sh.tabP[t], P1 = (Sum)sh.tabP[t + 1];
+        const Sum W0 = (Sum)sh.tabP[t - G::W256], W1 = (Sum)sh.tabP[t - G::W256 + 1];
+        const uint32_t c0 = (uint32_t)th.a, c1 = c0 + (uint32_t)G::CH;
+        // unbiased k: grows with P, falls with c
+        const uint32_t km = kmean_t<NARROW>(P0, c1);
+        uint32_t ok = flag01(km == kmean_t<NARROW>(P1, c0));
+        // drift (ref rice.hpp:85-95)
+        const uint32_t Llo = (uint32_t)(((P0 - W1) + 128u) >> 8), Lhi = (uint32_t)(((P1 - W0) + 128u) >> 8);
+        const uint32_t Ulo = (3u * Llo + 3u) >> 2, Uhi = (3u * Lhi + 3u) >> 2;
+        const uint32_t Dlo = Llo + (Llo + 3u) / 3u + 1u, Dhi = Lhi + (Lhi + 3u) / 3u + 1u;
+        const uint64_t Xlo = NARROW ? (uint64_t)((uint32_t)P0 + (c0 >> 1)) : (uint64_t)P0 + (c0 >> 1);
+        const uint64_t Xhi = NARROW ? (uint64_t)((uint32_t)P1 + (c1 >> 1)) : (uint64_t)P1 + (c1 >> 1);
+        const uint32_t act_never = flag01(Xhi < (uint64_t)c0), act_always = flag01(Xlo >= (uint64_t)c1);
+        const uint32_t up_always = flag01(Xhi < (uint64_t)Ulo * c0), up_never = flag01(Xlo >= (uint64_t)Uhi * c1);
+        const uint32_t dn_always = flag01(Xlo >= (uint64_t)Dhi * c1), dn_never = flag01(Xhi < (uint64_t)Dlo * c0);
+        ok &= act_never | (act_always & (up_always | up_never) & (dn_always | dn_never));
+        const int32_t drift = (int32_t)((act_never ^ 1u) & up_always) - (int32_t)((act_never ^ 1u) & dn_always);
+        // micro window (ref rice.hpp:97-105): the counts over the 96 before the chunk, what enters and what leaves
+        const uint32_t d0 = window_flags<G>(sh.tabF, t), din = sh.tabF[t], dout = sh.tabF[t - G::W96];
+        const int32_t l0 = (int32_t)(d0 & 0xFFFFu), z0 = (int32_t)(d0 >> 16);
+        const uint32_t big_always = flag01(l0 - (int32_t)(dout & 0xFFFFu) >= 72), big_never = flag01(l0 + (int32_t)(din & 0xFFFFu) < 72);
+        // The zero count sits near its threshold on ordinary material (the flag marks u < 2^k, about four samples in
+        // five), so the interval [z0 - leaving, z0 + entering] straddles 77 more often than not: walk the count
+        // itself over the chunk's states from the flag masks of the two chunks involved.
+        uint32_t sml_always, sml_never;
+        {
+            const uint32_t zin = sh.tabZM[t], zout = sh.tabZM[t - G::W96];
+            int32_t z = z0, zmin = z0, zmax = z0;
+#pragma unroll
+            for (int i = 0; i + 1 < G::CH; ++i) {
+                z += (int32_t)((zin >> i) & 1u) - (int32_t)((zout >> i) & 1u);
+                zmin = z < zmin ? z : zmin;
+                zmax = z > zmax ? z : zmax;
+            }
+            sml_always = flag01(zmin >= 77);
+            sml_never = flag01(zmax < 77);
+        }
+        ok &= big_always | (big_never & (sml_always | sml_never));
+        int32_t bias = drift + (int32_t)big_always - (int32_t)((big_always ^ 1u) & sml_always);
+        bias = bias < -1 ? -1 : (bias > 1 ? 1 : bias);
+        int bk = (int)km + bias;
+        bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
+        const uint32_t k = (uint32_t)bk;
+        // the values themselves: nothing small, nothing beyond the escape
+        ok &= flag01(th.umin > 4u);
+        uint32_t any = 0;
+        Sum ksum = 0;  // (32 bits on the narrow path: the block's whole sum of u is below kNarrowLimit)
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) {
+            any |= th.cs[l];
+            ksum += (Sum)(th.cs[l] >> k) << l;
+        }
+        if (ZR) ok &= flag01((any >> ((k + 3u) < 24u ? (k + 3u) : 24u)) == 0u);
+        if (ok == 0u) return false;
+        const Sum rice = ksum + (uint32_t)G::CH * (1u + k);
+        th.crice = rice;
+        th.cbin = rice + 2u * (uint32_t)G::CH;
+        th.czr = rice + 2u * (uint32_t)G::CH;
+        th.chasrun = 0;
+        return true;
+    }
+}
+
+template <class G>
+LACX_HD bool phase_b_quick_dispatch(Thread<G>& th, const Smem<G>& sh, bool narrow, bool zr) {
+    if (narrow) return zr ? phase_b_quick<G, true, true>(th, sh) : phase_b_quick<G, true, false>(th, sh);
+    return zr ? phase_b_quick<G, false, true>(th, sh) : phase_b_quick<G, false, false>(th, sh);
 }
 
 // Exact lower bound on min(rice, static, zero-run, bin) of a candidate, from four block sums:
@@ -1144,7 +1296,7 @@ LACX_HD bool partitions_chunk_aligned(uint32_t n, int max_p) {
     return max_p > 0 && (n % ((uint32_t)G::CH << max_p)) == 0u;
 }
 
-// All partition orders in one pass (32-bit arithmetic: requires total sum of u < 2^31).
+// All partition orders in one pass (32-bit arithmetic: requires total sum of u < kNarrowLimit).
 // Same numbers as partition_pass<G, true> run for p = 1..max_p.
 template <class G, bool ZR = true, class Flush>
 LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, Flush&& flush) {
@@ -1190,7 +1342,7 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     uint32_t x1 = peek_u<G>(sh, a + 1u, n), x2 = peek_u<G>(sh, a + 2u, n), x3 = peek_u<G>(sh, a + 3u, n);
     // One sample of the chunk for every order.  FIRST: the chunk's first sample, the only one that can be the first
     // of a partition (partitions start on chunk boundaries here) and then takes the partition's initial k.
-    // kin <= 31 throughout (sums < 2^31, see kmean32) and u < 2^31, so u >> kin needs no k >= 31 special case.
+    // kin <= 30 throughout (see kmean32), so u >> kin needs no k >= 31 special case.
     auto sample = [&](int i, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const uint32_t j = a + (uint32_t)i;

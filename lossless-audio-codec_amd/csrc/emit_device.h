@@ -44,7 +44,7 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
                                           uint32_t* __restrict__ err_flag, Resolve&& resolve, const int tid,
                                           const bool ablate_stores, const uint32_t slot_bytes STAMP_PARAMS) {
     (void)out;
-    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    const bool narrow = sh.tabP[G::T] < kNarrowLimit;
     const bool adaptive0 = sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3;  // stateful Rice::adapt_k walk
     if (adaptive0) {
         if (narrow) {

@@ -255,6 +255,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
             if (tid == 0) {
                 sh.has4[parity] = 0;
+                sh.bqcount = 0;
                 int next = best_key == ~0ull ? -1 : (int)(best_key & 15u);
                 if (next >= 0 && !(prm.debug_skip & 128u) && candidate_pruned(best_key >> 4, next, sh.best_bits, sh.best_cand)) next = -1;
                 sh.next_cand = next;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         STAMP(3);
         __syncthreads();  // B1b: the wave totals of the scan
         const uint64_t total_u = scan_pz_part2(sh, tid, sr);
-        const bool narrow = total_u < (1ull << 31);  // all prefix sums fit 32 bits (uniform)
+        const bool narrow = total_u < kNarrowLimit;  // all prefix sums fit 32 bits (uniform)
         const bool ksums = narrow && !(prm.debug_skip & 262144u);
         if (!(prm.debug_skip & 1u)) {
             if (ksums) ksums_wave(th, pt, pt256, tid); else plane_totals_wave(th, pt, pt256, tid);
@@ -311,15 +312,55 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         } else {
             // the zero-run cost only matters when the residual has a run of >= 4 zeros somewhere
             const bool zr = prm.zero_run && sh.has4[parity] != 0u;
-            phase_b_dispatch<G>(th, sh, k0, narrow, zr, n == (uint32_t)G::MAXN);
+            const bool full = n == (uint32_t)G::MAXN;
+            if (G::T == 64 || (prm.debug_skip & 524288u)) {
+                phase_b_dispatch<G>(th, sh, k0, narrow, zr, full);
+                if ((uint32_t)th.a >= n) {
+                    th.crice = th.cbin = th.czr = 0;
+                    th.chasrun = 0;
+                }
+            } else {
+                // Three chunks in four need no walk (phase_b_quick); the others are queued and walked after the barrier,
+                // densely packed over the lanes of as few waves as it takes.
+                const bool live = (uint32_t)th.a < n;
+                bool quick = false;
+                if (tid >= 64 && live) quick = phase_b_quick_dispatch<G>(th, sh, narrow, zr);
+                if (!quick) {
+                    th.crice = th.cbin = th.czr = 0;
+                    th.chasrun = 0;
+                }
+                if (tid >= 64) {
+                    const unsigned long long slow = __ballot(live && !quick);  // (wave-uniform)
+                    if (slow != 0ull) {
+                        uint32_t base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(&sh.bqcount, (uint32_t)__popcll(slow));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (live && !quick) sh.bqueue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(slow >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)slow, 0u))] = (uint16_t)tid;
+                    }
+                }
+                STAMP(11);
+                __syncthreads();  // Bq: the queue is complete
+                // Wave 0 walks its own chunks (the first 1024 samples, where the windows are still filling); waves 1..15
+                // take the queue in blocks of 64, those that share a SIMD with wave 0 (4, 8, 12) last.
+                if (tid < 64) {
+                    if (live) phase_b_dispatch<G>(th, sh, k0, narrow, zr, full, false);
+                } else {
+                    const int w = tid >> 6;
+                    const int order = (w & 3) ? (w - 1 - (w >> 2)) : (11 + (w >> 2));  // 1,2,3,5,6,7,... -> 0..11; 4,8,12 -> 12,13,14
+                    const uint32_t qn = sh.bqcount;
+                    for (uint32_t e0 = (uint32_t)order * 64u; e0 < qn; e0 += 15u * 64u) {  // wave-uniform trip count
+                        const uint32_t e = e0 + (uint32_t)(tid & 63);
+                        if (e < qn) phase_b_queued<G>(th, sh, (int)sh.bqueue[e], k0, narrow, zr, full);
+                    }
+                }
+            }
         }
         STAMP(12);
         {
-            const bool active = (uint32_t)th.a < n;
-            const uint64_t r0 = wave_sum_u64(active ? th.crice : 0ull);
-            const uint64_t r1 = wave_sum_u64(active ? th.cbin : 0ull);
-            const uint64_t r2 = wave_sum_u64(active ? th.czr : 0ull);
-            const uint32_t r3 = wave_or_u32(active ? th.chasrun : 0u);
+            const uint64_t r0 = wave_sum_u64(th.crice);
+            const uint64_t r1 = wave_sum_u64(th.cbin);
+            const uint64_t r2 = wave_sum_u64(th.czr);
+            const uint32_t r3 = wave_or_u32(th.chasrun);
             if ((tid & 63) == 0) {
                 atomicAdd(&acc[0], (unsigned long long)r0);
                 atomicAdd(&acc[1], (unsigned long long)r1);
@@ -367,7 +408,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         scan_pz_part2(sh, tid, sr);
         __syncthreads();
     }
-    const bool pnarrow = sh.tabP[G::T] < (1ull << 31);
+    const bool pnarrow = sh.tabP[G::T] < kNarrowLimit;
     STAMP(16);
     if (max_p > 0) {
         {
@@ -411,7 +452,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
             // all orders in one walk (every full block, every probe); without a run of >= 4 zeros in the
             // block no partition can have one, so the zero-run costs are not needed.  Narrow sums: every segment total
-            // stays below 2^32 (sum of u < 2^31, at most 35 bits of overhead per sample), so 32-bit LDS atomics on the
+            // stays below 2^32 (sum of u < kNarrowLimit, at most 36 bits of overhead per sample), so 32-bit LDS atomics on the
             // low words of the (zeroed) 64-bit accumulators suffice.
             // One atomic per accumulator and segment of neighbouring lanes (see seg_sum_u32): the lanes of a partition of
             // order p are (n >> p) / CH neighbours -- a power of two for every full block and every probe; other sizes

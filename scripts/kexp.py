@@ -57,7 +57,7 @@ def child(secs, kind, bd, sr):
         import ctypes as C
         buf = (C.c_ulonglong * 40)()
         lacx.lib().lacx_debug_stamps(buf)
-        names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "part: quick", "phase_a", "part: queued", "B3 wait", "-", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish", "-"]
+        names = ["stage", "score+select", "pass1: all bounds", "resid+store+scan1", "Bsel wait", "pass1 barrier", "scan2+planes", "part: quick", "phase_a", "part: queued", "B3 wait", "quick+enqueue", "phase_b", "reduce", "B5 wait", "-", "part: r+scan", "grp+scan", "seg_static", "part pass", "B wait", "choose+final", "(realtime)", "emit: plan+nx scan", "emit: phase A", "emit: walk 1", "emit: bit scan", "emit: zero tile", "emit: walk 2", "emit: barrier", "emit: copy+publish", "-"]
         idx = [i for i in range(32) if i != 22]
         tot = sum(buf[i] for i in idx)
         waves = max(1, buf[32])

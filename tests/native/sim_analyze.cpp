@@ -109,7 +109,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         scans_after_r(sh);
         plane_totals(sh, th);
         const uint32_t k0 = initial_k_from_planes(sh.planeTot256[0], n);
-        const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
+        const bool narrow = !(force_wide & 1) && sh.tabP[G::T] < kNarrowLimit;
         for (int t = 0; t < G::T; ++t) {
             if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
         }
@@ -117,22 +117,54 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         bool zr = false;
         for (int t = 0; t < G::T; ++t) zr = zr || th[t].has4 != 0;
         zr = zr && zero_run;
+        static const bool qstats = getenv("LACX_SIM_QSTATS") != nullptr;
+        uint32_t nquick = 0, nchunks = 0;
+        const bool full = n == (uint32_t)G::MAXN;
+        // The kernel's order: the costs of a chunk without the walk where that is provably the same thing
+        // (phase_b_quick); the other chunks of waves 1.. are queued and walked afterwards by whichever lane the queue
+        // hands them to; wave 0's chunks are always walked in place.
+        sh.bqcount = 0;
         for (int t = 0; t < G::T; ++t) {
-            phase_b_dispatch<G>(th[t], sh, k0, narrow, zr, n == (uint32_t)G::MAXN);
-            if ((uint32_t)th[t].a < n) {
-                sh.acc[0][0] += th[t].crice;
-                sh.acc[0][1] += th[t].cbin;
-                sh.acc[0][2] += th[t].czr;
-                sh.acc[0][3] += th[t].chasrun;
+            const bool live = (uint32_t)th[t].a < n;
+            bool quick = false;
+            if (G::T > 64 && t >= 64 && live && !(force_wide & 16)) quick = phase_b_quick_dispatch<G>(th[t], sh, narrow, zr);
+            if (quick && (force_wide & 32)) {  // self-check: the walk must agree
+                const unsigned long long qr = th[t].crice, qb = th[t].cbin, qz = th[t].czr;
+                const uint32_t qh = th[t].chasrun;
+                phase_b_dispatch<G>(th[t], sh, k0, narrow, zr, full);
+                if (qr != th[t].crice || qb != th[t].cbin || (zr && (qz != th[t].czr || qh != th[t].chasrun))) {
+                    fprintf(stderr, "phase_b_quick disagrees with the walk: cand %d chunk %d\n", cand, t);
+                    delete shp;
+                    return 2;
+                }
             }
+            if (!quick) {
+                th[t].crice = th[t].cbin = th[t].czr = 0;
+                th[t].chasrun = 0;
+                if (live && G::T > 64 && t >= 64 && !(force_wide & 16)) sh.bqueue[sh.bqcount++] = (uint16_t)t;
+                else if (live) phase_b_dispatch<G>(th[t], sh, k0, narrow, zr, full);
+            }
+            nchunks += live;
+            nquick += quick;
         }
+        for (uint32_t e = 0; e < sh.bqcount; ++e) {  // lane e % 64 of some wave walks queued chunk e
+            Thread<G>& lane = th[64 + (e % (uint32_t)(G::T > 64 ? G::T - 64 : 1))];
+            phase_b_queued<G>(lane, sh, (int)sh.bqueue[e], k0, narrow, zr, full);
+        }
+        for (int t = 0; t < G::T; ++t) {
+            sh.acc[0][0] += th[t].crice;
+            sh.acc[0][1] += th[t].cbin;
+            sh.acc[0][2] += th[t].czr;
+            sh.acc[0][3] += th[t].chasrun;
+        }
+        if (qstats) fprintf(stderr, "phase_b: n=%u cand %d quick chunks %u of %u, queued %u\n", n, cand, nquick, nchunks, sh.bqcount);
         score_candidate(sh, cand, n, zero_run, k0, sh.planeTot[0], sh.acc[0]);
     }
     // partition search on the winner
     const int best = sh.best_cand;
     for (int t = 0; t < G::T; ++t) phase_r(th[t], sh, best);
     scans_after_r(sh);
-    const bool pnarrow = !(force_wide & 1) && sh.tabP[G::T] < (1ull << 31);
+    const bool pnarrow = !(force_wide & 1) && sh.tabP[G::T] < kNarrowLimit;
     PartMem<G>& pm = sh.xp.part;
     int max_p = 0;
     if (partitioning && n >= (uint32_t)kMinPartition) max_p = max_partition_order(n);
@@ -171,6 +203,7 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
         const bool fused = pnarrow && !(force_wide & 2) && partitions_chunk_aligned<G>(n, max_p);
         const bool quick = fused && !(zero_run && sh.best_hasrun) && !(force_wide & 8);
         pm.qcount = 0;
+        if (getenv("LACX_SIM_QSTATS")) fprintf(stderr, "partition: n=%u narrow %d hasrun %d fused %d quick %d total_u %llu\n", n, (int)pnarrow, (int)sh.best_hasrun, (int)fused, (int)quick, (unsigned long long)sh.tabP[G::T]);
         for (int t = 0; t < G::T; ++t) {
             if (quick) {  // the kernel's default: no sample walk where the Rice parameter is constant over the chunk
                 partition_quick<G>(th[t], sh, max_p, flushq, [&pm](uint32_t entry, bool ambiguous) { if (ambiguous) pm.queue[pm.qcount++] = (uint16_t)entry; });
@@ -236,7 +269,7 @@ int run_emit_sim(const int32_t* x, uint32_t n, const ChannelPlan* plan, uint8_t*
             if (v < mn) mn = v;
         }
     }
-    const bool narrow = sh.tabP[G::T] < (1ull << 31);
+    const bool narrow = sh.tabP[G::T] < kNarrowLimit;
     if (sh.p == 0 && (sh.part_mode_k[0] >> 5) != 3) {
         for (int t = 0; t < G::T; ++t) {
             if (narrow) phase_a<G, true>(th[t], sh); else phase_a<G, false>(th[t], sh);
@@ -303,7 +336,8 @@ int sim_block_encode(const int32_t* x, uint32_t n, int zero_run, int partitionin
 // geo: 0 = <16,1024> (full blocks), 1 = <4,64> (probe windows)
 // force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;
 // bit 1: use the per-order partition passes even where the fused pass applies; bit 2: no candidate pruning;
-// bit 3: the fused walk instead of partition_quick
+// bit 3: the fused walk instead of partition_quick; bit 4: no phase_b_quick; bit 5: check every phase_b_quick result
+// against the walk
 int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
                    ChannelPlan* out) {
     if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);

@@ -397,6 +397,29 @@ def test_zero_run_structures(gpu, oracle):
         assert gpu.lacx.Encoder(12, 2, 48000, bd).encode(left, right) == oracle.encode(left, right, 48000, bd, 2, threads=8), it
 
 
+def test_loud_blocks_around_the_32_bit_sum_limit(gpu, oracle):
+    """Residual sums in [2^31, 2^32) and on either side of kNarrowLimit (analyze_core.h): the 32-bit paths of the analysis,
+    the partition search and the emit up to the limit, the 64-bit ones beyond -- blocks through Block::Encoder, then the
+    same material as a 24-bit stereo stream (probe, stereo decision, fused emit)."""
+    rng = np.random.default_rng(41)
+    be = gpu.lacx.BlockEncoder()
+    tone, _ = gpu.synth.synth_pcm(16384, 1, 24, 96000, seed=12, kind="music")
+    blocks = [rng.integers(-amp, amp + 1, size=16384).astype(np.int32)
+              for amp in (140_000, 185_000, 250_000, 261_000, 262_100, 263_500, 275_000, 600_000)]
+    for gain in (6, 14, 30):
+        loud = np.clip(tone.astype(np.int64) * gain, -(1 << 23), (1 << 23) - 1).astype(np.int32)
+        blocks.append((loud + rng.integers(-150_000, 150_001, size=loud.size)).astype(np.int32))
+    blocks.append(rng.integers(-200_000, 200_001, size=9000).astype(np.int32))
+    for i, x in enumerate(blocks):
+        assert be.encode(x) == oracle.block_encode(x), i
+    lim = (1 << 23) - 1
+    left = np.clip(np.concatenate(blocks[:6]), -lim - 1, lim).astype(np.int32)
+    right = np.clip(np.concatenate(blocks[5:11]), -lim - 1, lim).astype(np.int32)[:left.size]
+    left = left[:right.size]
+    for sm in (0, 1, 2):
+        assert gpu.lacx.Encoder(12, sm, 96000, 24).encode(left, right) == oracle.encode(left, right, 96000, 24, sm, threads=8), sm
+
+
 def test_begin_end_interface(gpu, oracle):
     """The two-halves interface (enqueue, collect later) with two encoders alternating: same bytes."""
     import torch

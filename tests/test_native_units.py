@@ -34,7 +34,7 @@ def test_x87_softfloat_matches_long_double():
 def sim():
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "libsim.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-I", CSRC,
                            os.path.join(ROOT, "tests", "native", "sim_analyze.cpp"), "-o", so])
     lib = C.CDLL(so)
     lib.sim_kmean_check.restype = C.c_uint64
@@ -74,10 +74,32 @@ def test_simulated_kernel_plans_match_oracle(pkg, oracle, sim, kind):
     cases = [(left[:16384], 0), (s[:16384], 0), (m[16384:], 0), (left[100:356], 1), (s[5000:5256], 0),
              (right[3:4100], 0), (left[9:40], 0), (m[:1], 0), (s[:13], 0), (left[:13312], 0)]
     for i, (x, geo) in enumerate(cases):
-        for wide in (0, 1, 2, 8):
+        for wide in (0, 1, 2, 8, 16, 32, 33):
             _check(sim, oracle, x, geo, True, True, wide)
     _check(sim, oracle, left[:16384], 0, False, True, 0)
     _check(sim, oracle, left[:16384], 0, True, False, 0)
+
+
+def test_blocks_around_the_32_bit_sum_limit(pkg, oracle, sim):
+    """The 32-bit fast paths hold for residual sums below kNarrowLimit = 2^32 - 2^20 (analyze_core.h): loud blocks whose
+    sums land in [2^31, 2^32) and on either side of the limit, through the default variants, the forced 64-bit ones (1)
+    and with every phase_b_quick result checked against the walk (32) -- plan and emitted bytes against the oracle."""
+    rng = np.random.default_rng(41)
+    blocks = []
+    for amp in (140_000, 185_000, 250_000, 261_000, 262_100, 263_500, 275_000, 600_000):
+        blocks.append(rng.integers(-amp, amp + 1, size=16384).astype(np.int32))          # white: order 0 wins, sum ~ n * amp
+    tone, _ = pkg.synth.synth_pcm(16384, 1, 24, 96000, seed=12, kind="music")
+    for gain in (6, 14, 30):
+        loud = np.clip(tone.astype(np.int64) * gain, -(1 << 23), (1 << 23) - 1).astype(np.int32)
+        blocks.append((loud + rng.integers(-150_000, 150_001, size=loud.size)).astype(np.int32))   # predictable part + loud floor
+    blocks.append(rng.integers(-200_000, 200_001, size=9000).astype(np.int32))              # ragged size
+    out = (C.c_uint8 * (1 << 20))()
+    for x in blocks:
+        for wide in (0, 1, 32):
+            _check(sim, oracle, x, 0, True, True, wide)
+        xc = np.ascontiguousarray(x, dtype=np.int32)
+        nbytes = sim.sim_block_encode(xc.ctypes.data_as(C.POINTER(C.c_int32)), C.c_uint32(xc.size), 1, 1, 0, out, C.c_uint32(len(out)))
+        assert nbytes > 0 and bytes(out[:nbytes]) == oracle.block_encode(xc, True, True)
 
 
 def test_zero_run_bound_formula_is_a_lower_bound():
@@ -144,7 +166,7 @@ def test_kernel_phases_clean_under_sanitizers():
     over block shapes and materials that reach every path (narrow / 64-bit, zero-run, bin, partitions, emit tiles)."""
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, "sim_sanitize")
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC,
+    cmd = ["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC,
            os.path.join(ROOT, "tests", "native", "sim_analyze.cpp"),
            os.path.join(ROOT, "tests", "native", "sim_sanitize_main.cpp"), "-o", exe]
     built = subprocess.run(cmd, capture_output=True, text=True)
