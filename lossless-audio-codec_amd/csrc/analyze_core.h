@@ -242,6 +242,7 @@ struct Smem {
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
     uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
     uint16_t tabZM[G::T];     // phase A: bit i = sample i of the chunk has the "zero quotient" micro flag (phase_b_quick)
+    uint16_t tabUZ[G::T + 2]; // phase A: bit i = sample i of the chunk is zero ([T]: stays 0, "not a zero" past the slot)
     uint16_t bqueue[G::T];    // chunks whose adaptive costs need the walk (phase B), packed over the lanes of the waves
     uint32_t bqcount;
     uint32_t planeTot[2][32];    // per bit-plane population over the block (double buffered by candidate parity)
@@ -282,6 +283,7 @@ struct Thread {
     uint32_t chasrun;
     uint32_t has4;    // phase A: a run of >= 4 zeros lies in or ends in this chunk
     uint32_t umin;    // phase A: smallest u of the chunk
+    uint32_t zmask;   // phase A: bit i = sample i of the chunk is zero
 };
 
 template <class G>
@@ -798,8 +800,12 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
         fzm |= fz << i;
     }
     sh.tabF[th.tid] = cnt;
-    if constexpr (requires { sh.tabZM[0]; }) sh.tabZM[th.tid] = (uint16_t)fzm;
+    if constexpr (requires { sh.tabZM[0]; }) {
+        sh.tabZM[th.tid] = (uint16_t)fzm;
+        sh.tabUZ[th.tid] = (uint16_t)zm;
+    }
     th.umin = mn;
+    th.zmask = zm;
     // Zero-run mode can only matter when some run of >= 4 zeros exists (ref block/encoder.cpp:224-247 sets
     // has_run only then).  Such a run lies inside one chunk, or crosses into a chunk: then the zeros ending
     // just before the chunk plus the chunk's leading zeros reach 4.
@@ -977,15 +983,19 @@ LACX_HD void phase_b_queued(Thread<G>& th, const Smem<G>& sh, int t, uint32_t k0
     th.chasrun |= c.chasrun;
 }
 
+LACX_HD uint32_t census_code(uint32_t u);
+LACX_HD uint32_t census_shift_sum(uint32_t cen, uint32_t K);
+
 // Phase B of one chunk without the walk, where that is provably the same thing.  The Rice parameter in force for a sample
 // is a function of four running quantities (ref rice.hpp:68-113): the prefix sum P and count c (unbiased k), the sum of
 // the last 256 (drift) and the flag counts of the last 96 (micro window).  Over the CH samples of a chunk each of them
 // moves inside an interval known from the tables the block scans have already built -- P in [tabP[t], tabP[t+1]], the
 // sum leaving the 256-window in chunk t - W256's sum, the flags entering / leaving the 96-window in tabF[t] /
 // tabF[t - W96] (the zero flags sample by sample, from tabZM) -- and every comparison of adapt_k is monotone in them.  When all of them come out the same at both ends
-// of the intervals the parameter is one constant k for the whole chunk, and with no sample <= 4 (no zero, no short bin
-// code) and none above the zero-run escape the three adaptive costs are the chunk's k-sum from its plane counts:
-//   rice = sum (u >> k) + CH (1 + k),  bin = zero-run = rice + 2 CH.
+// of the intervals the parameter is one constant k for the whole chunk, and the three adaptive costs follow from the
+// chunk's k-sum (its plane counts), a census of its small values (bin) and its zero mask (zero-run):
+//   rice = sum (u >> k) + CH (1 + k);  bin and zero-run = rice + 2 CH when no sample is <= 4.
+// A sample above the zero-run escape sends the chunk to the walk as well.
 // Returns false (costs untouched) when any of this cannot be shown; the caller then walks the chunk (phase_b).
 // Needs the full windows behind the chunk (every wave but the first of a whole-block slot) and a complete chunk.
 template <class G, bool NARROW, bool ZR>
@@ -1039,8 +1049,7 @@ LACX_HD bool phase_b_quick(Thread<G>& th, const Smem<G>& sh) {
         int bk = (int)km + bias;
         bk = bk < 0 ? 0 : (bk > 31 ? 31 : bk);
         const uint32_t k = (uint32_t)bk;
-        // the values themselves: nothing small, nothing beyond the escape
-        ok &= flag01(th.umin > 4u);
+        // the values themselves
         uint32_t any = 0;
         Sum ksum = 0;  // (32 bits on the narrow path: the block's whole sum of u is below kNarrowLimit)
 #pragma unroll
@@ -1048,13 +1057,43 @@ LACX_HD bool phase_b_quick(Thread<G>& th, const Smem<G>& sh) {
             any |= th.cs[l];
             ksum += (Sum)(th.cs[l] >> k) << l;
         }
-        if (ZR) ok &= flag01((any >> ((k + 3u) < 24u ? (k + 3u) : 24u)) == 0u);
+        if (ZR) ok &= flag01((any >> ((k + 3u) < 24u ? (k + 3u) : 24u)) == 0u);  // nothing beyond the zero-run escape
         if (ok == 0u) return false;
         const Sum rice = ksum + (uint32_t)G::CH * (1u + k);
+        // bin: 2 for a zero, 3 for 1..4, else 2 + the Rice code -- the exceptions from a census of the small values
+        uint32_t n14 = 0, nbig = (uint32_t)G::CH, small_shifted = 0;
+        if (th.umin <= 4u) {
+            uint32_t cen = 0;
+#pragma unroll
+            for (int i = 0; i < G::CH; ++i) cen += census_code(sh.u[i * G::T + t] & 0x3FFFFFFFu);
+            n14 = ((cen >> 5) & 31u) + ((cen >> 10) & 31u) + ((cen >> 15) & 31u) + ((cen >> 20) & 31u);
+            nbig = (cen >> 25) & 31u;
+            small_shifted = census_shift_sum(cen, k);
+        }
         th.crice = rice;
-        th.cbin = rice + 2u * (uint32_t)G::CH;
-        th.czr = rice + 2u * (uint32_t)G::CH;
-        th.chasrun = 0;
+        th.cbin = (Sum)(2u * (uint32_t)G::CH + n14 + nbig * (1u + k)) + (ksum - small_shifted);
+        // zero-run: a sample inside a run of >= 4 zeros costs nothing until the run's last one pays the token; every
+        // other sample 2 + its Rice code.  Which samples those are follows from the chunk's zero mask, the zeros ending
+        // just before it and the three samples after it -- no sample is read.
+        uint32_t nin4 = 0, tokens = 0, hasrun = 0;
+        if (ZR && th.zmask != 0u) {
+            const uint32_t E = th.zmask | (((uint32_t)sh.tabUZ[t + 1] & 7u) << G::CH);
+            int32_t f = th.a - 1 - sh.tabNZ[t];
+#pragma unroll
+            for (int i = 0; i < G::CH; ++i) {
+                const uint32_t z = (E >> i) & 1u;
+                f = (f + 1) & (int32_t)(0u - z);
+                const uint32_t after = E >> (i + 1);
+                const uint32_t ahead = (after & 1u) == 0u ? 0u : ((after & 2u) == 0u ? 1u : ((after & 4u) == 0u ? 2u : 3u));
+                const uint32_t in4 = z & flag01((uint32_t)f + ahead >= 4u);
+                const uint32_t runend = in4 & ((after & 1u) ^ 1u);
+                nin4 += in4;
+                tokens += (5u + (((uint32_t)(f - 4)) >> 2)) & (0u - runend);
+                hasrun |= runend;
+            }
+        }
+        th.czr = ksum + (Sum)(((uint32_t)G::CH - nin4) * (3u + k) + tokens);
+        th.chasrun = hasrun;
         return true;
     }
 }

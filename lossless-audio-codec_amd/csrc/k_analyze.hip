@@ -174,7 +174,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     if (tid < 4) sh.acc[0][tid] = sh.acc[1][tid] = 0;
     if (tid < 33) (&sh.lbacc[0][0])[tid] = 0;
     if (tid < 2) sh.has4[tid] = 0;
-    if (tid == 0) sh.best_cand = -1;
+    if (tid == 0) {
+        sh.best_cand = -1;
+        sh.tabUZ[G::T] = sh.tabUZ[G::T + 1] = 0;  // "not a zero" past the slot (phase_b_quick)
+    }
     __syncthreads();
     STAMP(0);
 

@@ -156,7 +156,7 @@ def test_pruning_bound_on_zero_run_structures(pkg, oracle, sim):
             pos += gap
         blocks.append(x)
     for x in blocks:
-        for wide in (0, 4):
+        for wide in (0, 4, 32):
             _check(sim, oracle, x, 0, True, True, wide)
     _check(sim, oracle, np.zeros(256, np.int32), 1, True, True, 0)
 
