@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 output of scripts/profile_valu.sh (gpurun_out/<tag>/) into the tracked evidence under profiles/:
 
-  profiles/<tag>_kernel_stats_bench.csv          rocprofv3 --kernel-trace --stats of the default bench command
-  profiles/<tag>_kernel_stats_single_chunk.csv   the same with LACX_PIPE_CHUNKS=1 (no overlap between kernels)
+  profiles/<tag>_kernel_stats_bench.csv          rocprofv3 --kernel-trace --stats of the default bench command (under the
+                                                 profiler the payload's device-to-host copies run as blit kernels and slow
+                                                 the analysis kernel beside them: see scripts/profile_valu.sh)
+  profiles/<tag>_kernel_stats_direct_packer.csv  the same with LACX_DIRECT_PACKER=1 (no copies: the analysis kernel undisturbed)
+  profiles/<tag>_bench_line_*.json               the bench lines those two runs printed (HIP events inside the profiled process)
   profiles/<tag>_counters.json                   per kernel: mean of every counter per dispatch (SQ passes, GRBM, FETCH/WRITE)
   profiles/valu.json                             what bench.py's roofline.valu block reads (k_analyze<16,1024>)
   profiles/traffic.json                          what bench.py's roofline.traffic reads
@@ -40,10 +43,17 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
 counters = {k: {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in sorted(d.items())} for k, d in agg.items()}
 
 stats = {}
-for name, dst in (("trace", "kernel_stats_bench"), ("trace1", "kernel_stats_single_chunk")):
+for name, dst in (("trace", "kernel_stats_bench"), ("trace1", "kernel_stats_direct_packer")):
     for p in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(p, os.path.join(prof, f"{tag}_{dst}.csv"))
         stats[name] = {short(r["Name"]): r for r in csv.DictReader(open(p))}
+
+for name, dst in (("trace", "bench_line_under_rocprof"), ("trace1", "bench_line_under_rocprof_direct_packer")):
+    logp = os.path.join(src, name + ".log")
+    if os.path.exists(logp):
+        lines = [ln for ln in open(logp) if ln.startswith("{")]
+        if lines:
+            open(os.path.join(prof, f"{tag}_{dst}.json"), "w").write(lines[-1])
 
 full = next((k for k in counters if k.startswith("k_analyze") and "16,1024" in k), None)
 derived = {}
@@ -54,7 +64,7 @@ if full and "trace1" in stats and full in stats["trace1"]:
     clk_ghz = (c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) / dur_ns if c.get("GRBM_GUI_ACTIVE") else None
     derived = {
         "kernel": full,
-        "single_chunk_duration_ms": dur_ns / 1e6,
+        "single_chunk_duration_ms": dur_ns / 1e6,  # (the LACX_DIRECT_PACKER=1 trace: the kernel without blit copies beside it)
         "valu_wave_insts": c.get("SQ_INSTS_VALU"),
         "salu_wave_insts": c.get("SQ_INSTS_SALU"),
         "effective_clock_ghz_from_GRBM_GUI_ACTIVE": clk_ghz,
@@ -66,8 +76,9 @@ if full and "trace1" in stats and full in stats["trace1"]:
         "wave_cycles_share": {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in c and c.get("SQ_WAVE_CYCLES")},
         "lds_bank_conflict_share_of_lds_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
     }
-out = {"tag": tag, "command": "scripts/profile_valu.sh " + tag + " (bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end; SQ and GRBM passes "
-       "with LACX_PIPE_CHUNKS=1, FETCH/WRITE passes with the default pipeline; one rocprofv3 --pmc run per counter set)",
+out = {"tag": tag, "command": "scripts/profile_valu.sh " + tag + " (kernel traces: bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-other-workloads, as it runs and with "
+       "LACX_DIRECT_PACKER=1; counter passes: --steps 3 --warmup 1, one rocprofv3 --pmc run per counter set)",
+       "kernel_source_sha256": kernel_source_sha256(),
        "per_kernel_counter_means_per_dispatch": counters, "derived_k_analyze_full": derived}
 json.dump(out, open(os.path.join(prof, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))
@@ -91,7 +102,7 @@ if default and derived:
     # traffic of the default pipeline (3 launches per step)
     fk = counters[full]
     if "FETCH_SIZE" in fk and "WRITE_SIZE" in fk and "trace" in stats:
-        launches = int(stats["trace"][full]["Calls"]) // 4  # 1 warm-up + 3 timed steps
+        launches = int(stats["trace"][full]["Calls"]) // 13  # 3 warm-up + 10 timed steps
         # FETCH/WRITE passes ran with the default pipeline, the SQ passes single-chunk: keep only the pipeline's dispatches
         fvals = [v for v in agg[full]["FETCH_SIZE"]]
         wvals = [v for v in agg[full]["WRITE_SIZE"]]
