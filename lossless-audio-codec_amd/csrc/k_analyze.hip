@@ -309,6 +309,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own), prefixes in tabP
         STAMP(10);
         const uint32_t k0 = sh.cur_k0;
+        // (nothing derived from the thread index is carried from outside the candidate loop into phase B: the compiler
+        // would keep a dozen LDS addresses alive across pass 1 and the loop, in scratch memory)
+        asm volatile("" : "+v"(th.tid));
         if (prm.debug_skip & 4u) {
             th.crice = th.cbin = th.czr = 1;
             th.chasrun = 0;
