@@ -660,12 +660,11 @@ LACX_HD uint32_t bound_counts(const BoundPartials& b) {
 }
 
 // FULL: every position of every chunk lies inside the slot (n == MAXN, block-uniform): no per-sample masking.
-// lpc_off: the LPC candidates are switched off (diagnostic ablation).  out[c] of an unavailable LPC candidate is zeroed.
-template <class G, bool FULL, class M>
-LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundPartials* out /* 11 */) {
-    int32_t xh[G::CH + 12];
+// The window of a chunk: its CH samples and the twelve before it (as in phase_r_residual).
+template <class G, class M>
+LACX_HD void pass1_window(const Thread<G>& th, const M& sh, int32_t* xh /* CH + 12 */) {
 #pragma unroll
-    for (int i = 0; i < G::CH + 12; ++i) {  // the window, as in phase_r_residual
+    for (int i = 0; i < G::CH + 12; ++i) {
         const int d = i - 12;
         const int co = (d >= 0) ? d / G::CH : -((-d + G::CH - 1) / G::CH);
         const int el = d - co * G::CH;
@@ -673,6 +672,13 @@ LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundP
         const int32_t* col = &sh.xp.x[tt < 0 ? 0 : tt];
         xh[i] = (tt >= 0) ? col[el * G::T] : 0;
     }
+}
+
+// Fixed orders 0..4 and the FIR predictor -> out[0..5].
+template <class G, bool FULL, class M>
+LACX_HD void pass1_bounds_fixed(const Thread<G>& th, const M& sh, BoundPartials* out /* 6 */) {
+    int32_t xh[G::CH + 12];
+    pass1_window(th, sh, xh);
     const int32_t* x = xh + 12;
     const bool first = th.a == 0;  // the slot's first chunk: warm-up samples are taken raw (ref block/encoder.cpp:265-309)
     auto live = [&](int i, int32_t r) { return FULL ? r : ((i < th.cnt) ? r : 0); };
@@ -705,7 +711,17 @@ LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundP
 #pragma unroll
         for (int c = 0; c < 6; ++c) out[c] = b[c];
     }
-    for (int ci = 0; ci < 5; ++ci) {  // LPC orders 4, 6, 8, 10, 12 (open-loop Q15, ref lpc/lpc.cpp:38-61)
+}
+
+// The LPC candidates (orders 4, 6, 8, 10, 12: open-loop Q15, ref lpc/lpc.cpp:38-61) -> out[0..4].
+// lpc_off: the LPC candidates are switched off (diagnostic ablation).  out[c] of an unavailable LPC candidate is zeroed.
+template <class G, bool FULL, class M>
+LACX_HD void pass1_bounds_lpc(const Thread<G>& th, const M& sh, bool lpc_off, BoundPartials* out /* 5 */) {
+    int32_t xh[G::CH + 12];
+    pass1_window(th, sh, xh);
+    const int32_t* x = xh + 12;
+    auto live = [&](int i, int32_t r) { return FULL ? r : ((i < th.cnt) ? r : 0); };
+    for (int ci = 0; ci < 5; ++ci) {
         BoundPartials b;
         bound_init(b);
         const int ord = lpc_off ? 0 : (int)sh.lpc.used[ci];
@@ -731,8 +747,19 @@ LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundP
         else if (ord <= 8) lpc(std::integral_constant<int, 8>{});
         else if (ord <= 10) lpc(std::integral_constant<int, 10>{});
         else lpc(std::integral_constant<int, 12>{});
-        out[6 + ci] = b;
+        // (selects, not out[ci]: an array indexed by the loop counter lives in scratch memory)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            if (c == ci) out[c] = b;
+        }
     }
+}
+
+// all eleven (the host simulator's form)
+template <class G, bool FULL, class M>
+LACX_HD void pass1_bounds(const Thread<G>& th, const M& sh, bool lpc_off, BoundPartials* out /* 11 */) {
+    pass1_bounds_fixed<G, FULL>(th, sh, out);
+    pass1_bounds_lpc<G, FULL>(th, sh, lpc_off, out + 6);
 }
 
 // Horner from plane counts C[0..29] to A[k] = sum_j (u_j >> k), k = 0..kmax.

@@ -190,10 +190,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
         // addresses and masks derived from it and, at the 128-VGPR budget, spills them to scratch.
         asm volatile("" : "+v"(th.a));
-        BoundPartials bp[11];
         const bool lpc_off = (prm.debug_skip & 16u) != 0u;
-        if (n == (uint32_t)G::MAXN) pass1_bounds<G, true>(th, sh, lpc_off, bp);  // uniform
-        else pass1_bounds<G, false>(th, sh, lpc_off, bp);
         // bit_width(u | 1) + 1 = 33 - clz(u | 1) = 34 - lead_m per position.  A zero counts 2 that way and is worth 1 (the
         // wave's zero count takes the difference out); a position beyond the slot (r = 0) counts 2, is among those zeros
         // and is worth nothing (the wave's `beyond` takes the rest out).
@@ -202,26 +199,42 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         const int32_t left = (int32_t)n - (int32_t)((tid >> 6) * 64 * G::CH);  // samples of the slot from this wave's first one on
         const uint32_t valid = left <= 0 ? 0u : (left >= 64 * G::CH ? (uint32_t)(64 * G::CH) : (uint32_t)left);
         const uint32_t beyond = (uint32_t)(64 * G::CH) - valid;
-#pragma unroll
-        for (int c = 0; c < 12; c += 2) {
-            const uint32_t lo = per_thread - bp[c].msum, hi = c + 1 < 11 ? per_thread - bp[c + 1 < 11 ? c + 1 : c].msum : 0u;
+        auto reduce_pair = [&](int c0, const BoundPartials& b0, bool two, const BoundPartials& b1) {
+            const uint32_t lo = per_thread - b0.msum, hi = two ? per_thread - b1.msum : 0u;
             const uint32_t g2 = wave_sum_u32(lo | (hi << 16));
-            const uint32_t cnt0 = wave_sum_u32(bound_counts<G::CH>(bp[c]));
-            const uint32_t cnt1 = c + 1 < 11 ? wave_sum_u32(bound_counts<G::CH>(bp[c + 1 < 11 ? c + 1 : c])) : 0u;
+            const uint32_t cnt0 = wave_sum_u32(bound_counts<G::CH>(b0));
+            const uint32_t cnt1 = two ? wave_sum_u32(bound_counts<G::CH>(b1)) : 0u;
             if ((tid & 63) == 0) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int cc = c + h;
-                    if (cc < 11) {
+                    if (h == 0 || two) {
                         const uint32_t g = h ? (g2 >> 16) : (g2 & 0xFFFFu);
                         const uint32_t cnt = h ? cnt1 : cnt0;
                         const uint32_t nz = cnt & 0x7FFu, n4 = (cnt >> 11) & 0x7FFu, ends = cnt >> 22;
-                        atomicAdd(&sh.lbacc[cc][0], g - nz - beyond);
-                        atomicAdd(&sh.lbacc[cc][1], (nz - beyond) + (n4 << 16));
-                        atomicAdd(&sh.lbacc[cc][2], ends);
+                        atomicAdd(&sh.lbacc[c0 + h][0], g - nz - beyond);
+                        atomicAdd(&sh.lbacc[c0 + h][1], (nz - beyond) + (n4 << 16));
+                        atomicAdd(&sh.lbacc[c0 + h][2], ends);
                     }
                 }
             }
+        };
+        // The fixed orders and the FIR predictor first, summed over the wave before the LPC candidates start: their six
+        // sets of partials do not have to live through the LPC walks (where they did not fit the register file).
+        {
+            BoundPartials bf[6];
+            if (n == (uint32_t)G::MAXN) pass1_bounds_fixed<G, true>(th, sh, bf);  // uniform
+            else pass1_bounds_fixed<G, false>(th, sh, bf);
+#pragma unroll
+            for (int c = 0; c < 6; c += 2) reduce_pair(c, bf[c], true, bf[c + 1]);
+        }
+        asm volatile("" : "+v"(th.a));
+        {
+            BoundPartials bl[5];
+            if (n == (uint32_t)G::MAXN) pass1_bounds_lpc<G, true>(th, sh, lpc_off, bl);  // uniform
+            else pass1_bounds_lpc<G, false>(th, sh, lpc_off, bl);
+            reduce_pair(6, bl[0], true, bl[1]);
+            reduce_pair(8, bl[2], true, bl[3]);
+            reduce_pair(10, bl[4], false, bl[4]);
         }
     }
     STAMP(2);
