@@ -238,7 +238,10 @@ int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const 
  * src/codec/block/decoder.cpp:64-520.  The product's own check that a .lac gives back the PCM, on the device: one lane
  * per block (the format serialises everything inside a block), all blocks of the stream at once.
  * lacx_stream_parse: host only; the reference reader's structural rules for the header and the block table (versions 3
- * and 2; its 1 GiB cap on the decoded PCM is not taken over), LACX_E_INVALID otherwise.
+ * and 2), LACX_E_INVALID otherwise.  Two documented deviations from the reference reader: its 1 GiB cap on the decoded PCM
+ * is not taken over (it would refuse the 2 h stream), and a compressed block must stay below 2^29 bytes (the device
+ * reader's bit positions are 32-bit and relative to the block; the reference accepts any non-zero size that fits the
+ * file -- no encoder produces such a block: 16384 frames x 2 channels cost at most a few hundred KiB).
  * lacx_decode: left / right (right may be null for mono) are caller-owned arrays of `frames` int32 each; a malformed
  * block, a sample outside the bit depth or a residual magnitude the encoder's domain cannot produce (>= 2^30) gives
  * LACX_E_RUNTIME ("[decode-error] block=N ..." in lacx_decode_last_error, the reference throws std::runtime_error with
