@@ -1013,6 +1013,32 @@ LACX_HD void phase_b_queued(Thread<G>& th, const Smem<G>& sh, int t, uint32_t k0
 LACX_HD uint32_t census_code(uint32_t u);
 LACX_HD uint32_t census_shift_sum(uint32_t cen, uint32_t K);
 
+// Zero-run structure of one chunk from its zero mask (bits 0..CH-1; bits CH..CH+2 = the three samples after it) and the
+// number of zeros ending just before it: how many of its samples lie inside a run of >= 4 zeros (they cost nothing until
+// the run's last one pays the token, ref block/encoder.cpp:224-247), the tokens of the runs that end in the chunk,
+// whether one does, and whether the chunk's first sample is inside such a run.
+struct RunShape {
+    uint32_t nin4, tokens, hasrun, first_in4;
+};
+template <int CH>
+LACX_HD RunShape run_shape(uint32_t E, int32_t f) {
+    RunShape r{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const uint32_t z = (E >> i) & 1u;
+        f = (f + 1) & (int32_t)(0u - z);
+        const uint32_t after = E >> (i + 1);
+        const uint32_t ahead = (after & 1u) == 0u ? 0u : ((after & 2u) == 0u ? 1u : ((after & 4u) == 0u ? 2u : 3u));
+        const uint32_t in4 = z & flag01((uint32_t)f + ahead >= 4u);
+        const uint32_t runend = in4 & ((after & 1u) ^ 1u);
+        r.nin4 += in4;
+        r.tokens += (5u + (((uint32_t)(f - 4)) >> 2)) & (0u - runend);
+        r.hasrun |= runend;
+        if (i == 0) r.first_in4 = in4;
+    }
+    return r;
+}
+
 // Phase B of one chunk without the walk, where that is provably the same thing.  The Rice parameter in force for a sample
 // is a function of four running quantities (ref rice.hpp:68-113): the prefix sum P and count c (unbiased k), the sum of
 // the last 256 (drift) and the flag counts of the last 96 (micro window).  Over the CH samples of a chunk each of them
@@ -1102,23 +1128,10 @@ LACX_HD bool phase_b_quick(Thread<G>& th, const Smem<G>& sh) {
         // zero-run: a sample inside a run of >= 4 zeros costs nothing until the run's last one pays the token; every
         // other sample 2 + its Rice code.  Which samples those are follows from the chunk's zero mask, the zeros ending
         // just before it and the three samples after it -- no sample is read.
-        uint32_t nin4 = 0, tokens = 0, hasrun = 0;
-        if (ZR && th.zmask != 0u) {
-            const uint32_t E = th.zmask | (((uint32_t)sh.tabUZ[t + 1] & 7u) << G::CH);
-            int32_t f = th.a - 1 - sh.tabNZ[t];
-#pragma unroll
-            for (int i = 0; i < G::CH; ++i) {
-                const uint32_t z = (E >> i) & 1u;
-                f = (f + 1) & (int32_t)(0u - z);
-                const uint32_t after = E >> (i + 1);
-                const uint32_t ahead = (after & 1u) == 0u ? 0u : ((after & 2u) == 0u ? 1u : ((after & 4u) == 0u ? 2u : 3u));
-                const uint32_t in4 = z & flag01((uint32_t)f + ahead >= 4u);
-                const uint32_t runend = in4 & ((after & 1u) ^ 1u);
-                nin4 += in4;
-                tokens += (5u + (((uint32_t)(f - 4)) >> 2)) & (0u - runend);
-                hasrun |= runend;
-            }
-        }
+        RunShape rs{0u, 0u, 0u, 0u};
+        if (ZR && th.zmask != 0u)
+            rs = run_shape<G::CH>(th.zmask | (((uint32_t)sh.tabUZ[t + 1] & 7u) << G::CH), th.a - 1 - sh.tabNZ[t]);
+        const uint32_t nin4 = rs.nin4, tokens = rs.tokens, hasrun = rs.hasrun;
         th.czr = ksum + (Sum)(((uint32_t)G::CH - nin4) * (3u + k) + tokens);
         th.chasrun = hasrun;
         return true;
@@ -1480,14 +1493,16 @@ LACX_HD void partition_fused(const Thread<G>& th, const Smem<G>& sh, int max_p, 
 LACX_HD uint32_t census_code(uint32_t u) { return 1u << (5u * (u < 5u ? u : 5u)); }
 
 template <class G>
-LACX_HD uint32_t small_census(const Thread<G>& th, const Smem<G>& sh, uint32_t* u_first) {
-    uint32_t cen = 0;
+LACX_HD uint32_t small_census(const Thread<G>& th, const Smem<G>& sh, uint32_t* u_first, uint32_t* zmask) {
+    uint32_t cen = 0, zm = 0;
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
         const uint32_t u = sh.u[i * G::T + th.tid];
         if (i == 0) *u_first = u;
         cen += census_code(u);
+        zm |= flag01(u == 0u) << i;
     }
+    *zmask = zm;
     return cen;
 }
 
@@ -1508,7 +1523,8 @@ LACX_HD void partition_quick(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     const uint32_t Pa = (uint32_t)sh.tabP[t];                 // P_{a-1}
     const uint32_t csum = (uint32_t)sh.tabP[t + 1] - Pa;      // sum of the chunk
     uint32_t u_first;
-    const uint32_t cen = small_census(th, sh, &u_first);
+    uint32_t zmask_unused;
+    const uint32_t cen = small_census(th, sh, &u_first, &zmask_unused);
     const uint32_t u_last = sh.u[(G::CH - 1) * G::T + t];
     const uint32_t code_first = census_code(u_first);
     // a / (n >> p) without a division when n is a power of two (every full block, every probe; block-uniform)
@@ -1549,9 +1565,133 @@ LACX_HD void partition_quick(const Thread<G>& th, const Smem<G>& sh, int max_p, 
     }
 }
 
-// One queued (chunk, order) pair of partition_quick: the plain walk over the chunk's samples (32-bit sums, no zero-run
-// costs, the whole chunk inside one partition).
-template <class G, class Flush>
+// ---------------------------------------------------------------------------------------------
+// The same search for a block WITH a run of >= 4 zeros: the zero-run cost of every partition is needed too.  With the
+// parameter constant it is the k-sum plus 3 + K for every sample outside a run of >= 4 zeros plus the tokens of the runs
+// that end in the chunk (run_shape: from the zero mask alone) -- unless the partition cuts a run (ref
+// block/encoder.cpp:224-247 counts runs per partition).  A run reaching back past the partition's first sample changes,
+// past the head chunk, one thing only: the token, when the run ends inside the chunk, counts the run from the
+// partition's first sample.  In the head chunk the first samples may drop out of the run, a run going on past the
+// partition's last sample ends there, and a sample above the zero-run escape costs 32 bits flat: those (chunk, order)
+// pairs are walked.  Classification first (partition_quick_prepare), so that a wave whose pairs mostly need the walk can
+// take partition_fused instead; then the costs (partition_quick_costs).
+// ---------------------------------------------------------------------------------------------
+template <class G>
+struct QuickPrep {
+    uint32_t Pa, u_first, cen, code_first;
+    uint32_t E;
+    int32_t f0;
+    RunShape rs;
+    uint32_t amb;                       // bit q: (chunk, order q + 1) needs the walk
+    uint32_t Kpack[(G::MAXP + 3) / 4];  // the constant parameter of order q + 1, a byte each
+};
+
+// A wave whose chunks have more ambiguous (chunk, order) pairs than this walks all orders at once instead
+// (partition_fused): the walks of that many pairs, packed 64 to a trip, cost more than the one walk of everything.
+constexpr uint32_t kQuickMaxPairs = 256;
+
+template <class G>
+LACX_HD void partition_quick_prepare(const Thread<G>& th, const Smem<G>& sh, int max_p, QuickPrep<G>& qp) {
+    const bool live = th.cnt > 0;
+    const uint32_t n = th.n;
+    const int t = th.tid;
+    const uint32_t a = (uint32_t)th.a;
+    qp.Pa = (uint32_t)sh.tabP[t];                              // P_{a-1}
+    const uint32_t csum = (uint32_t)sh.tabP[t + 1] - qp.Pa;    // sum of the chunk
+    uint32_t zmask;
+    qp.cen = small_census(th, sh, &qp.u_first, &zmask);
+    const uint32_t u_last = sh.u[(G::CH - 1) * G::T + t];
+    qp.code_first = census_code(qp.u_first);
+    // zero-run structure of the chunk as it stands in the block (no partition cutting a run)
+    qp.E = zmask | (flag01(peek_u<G>(sh, a + (uint32_t)G::CH, n) == 0u) << G::CH) |
+           (flag01(peek_u<G>(sh, a + (uint32_t)G::CH + 1u, n) == 0u) << (G::CH + 1)) |
+           (flag01(peek_u<G>(sh, a + (uint32_t)G::CH + 2u, n) == 0u) << (G::CH + 2));
+    qp.f0 = (int32_t)a - 1 - sh.tabNZ[t];
+    qp.rs = run_shape<G::CH>(qp.E, qp.f0);
+    uint32_t any = 0;
+#pragma unroll
+    for (int l = 0; l < G::LV; ++l) any |= th.cs[l];
+    const bool n_pow2 = (n & (n - 1u)) == 0u;
+    const int log2n = 31 - clz32(n);
+    qp.amb = 0;
+#pragma unroll
+    for (int w = 0; w < (G::MAXP + 3) / 4; ++w) qp.Kpack[w] = 0;
+#pragma unroll
+    for (int q = 0; q < G::MAXP; ++q) {
+        if (q >= max_p) continue;
+        const int p = q + 1;
+        const uint32_t base = n >> p;
+        const uint32_t part = !live ? 0u : (n_pow2 ? a >> (log2n - p) : a / base);
+        const uint32_t s = part * base;
+        const uint32_t Sa = qp.Pa - (uint32_t)sh.tabP[s / (uint32_t)G::CH];  // sum of the partition's samples before a
+        const uint32_t ca = a - s;                                            // ... and their number
+        const bool head = ca == 0u;
+        const uint32_t klo = kmean32(head ? qp.u_first : Sa, ca + (uint32_t)G::CH - 1u);
+        const uint32_t khi = kmean32(Sa + csum - u_last, head ? 1u : ca);
+        const bool cut_front = (qp.E & 1u) != 0u && (uint32_t)qp.f0 > ca;  // opens with a zero of a run that began before the partition
+        const bool cut_back = ca + (uint32_t)G::CH == base && ((qp.E >> (G::CH - 1)) & 3u) == 3u;  // last chunk, its last sample and the next one zero
+        const bool escape = (any >> ((klo + 3u) < 24u ? (klo + 3u) : 24u)) != 0u;
+        const bool ambiguous = klo != khi || (cut_front && head) || cut_back || escape;
+        qp.Kpack[q >> 2] |= klo << (8 * (q & 3));
+        qp.amb |= (live && ambiguous) ? (1u << q) : 0u;
+    }
+}
+
+template <class G, class Flush, class Enqueue>
+LACX_HD void partition_quick_costs(const Thread<G>& th, const Smem<G>& sh, int max_p, const QuickPrep<G>& qp, Flush&& flush,
+                                   Enqueue&& enqueue) {
+    // (chunks are complete or empty here; an empty chunk still takes part in the wave-wide steps of `enqueue`)
+    const bool live = th.cnt > 0;
+    const uint32_t n = th.n;
+    const int t = th.tid;
+    const uint32_t a = (uint32_t)th.a;
+    const bool n_pow2 = (n & (n - 1u)) == 0u;
+    const int log2n = 31 - clz32(n);
+    const uint32_t open_run = (uint32_t)ctz32(~qp.E);  // zeros the chunk opens with (counting on into the three samples after it)
+#pragma unroll
+    for (int q = 0; q < G::MAXP; ++q) {
+        if (q >= max_p) continue;
+        const int p = q + 1;
+        const uint32_t base = n >> p;
+        const uint32_t part = !live ? 0u : (n_pow2 ? a >> (log2n - p) : a / base);
+        const uint32_t sidx = (2u << (p - 1)) - 2u + part;
+        const uint32_t ca = a - part * base;
+        const bool head = ca == 0u;
+        const bool ambiguous = ((qp.amb >> q) & 1u) != 0u;
+        enqueue((uint32_t)t | ((uint32_t)q << 12), ambiguous);
+        const bool quick = live && !ambiguous;  // (the others pass zeros: every lane of the wave reaches the flush)
+        const uint32_t K = (qp.Kpack[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        uint32_t shifted = 0;  // sum of u >> K over the chunk
+#pragma unroll
+        for (int l = 0; l < G::LV; ++l) shifted += (th.cs[l] >> K) << l;
+        const uint32_t k_a = (uint32_t)sh.xp.part.seginfo[sidx].ak;
+        const uint32_t rc_a = (qp.u_first >> k_a) + 1u + k_a;             // head only
+        const uint32_t ncon = (uint32_t)G::CH - (head ? 1u : 0u);         // samples costed at K
+        const uint32_t cen_con = qp.cen - (head ? qp.code_first : 0u);
+        if (head) shifted -= qp.u_first >> K;
+        const uint32_t rice = shifted + ncon * (1u + K) + (head ? rc_a : 0u);
+        // bin: 2 for a zero, 3 for 1..4, else 2 + the Rice code
+        const uint32_t n14 = ((cen_con >> 5) & 31u) + ((cen_con >> 10) & 31u) + ((cen_con >> 15) & 31u) + ((cen_con >> 20) & 31u);
+        const uint32_t nbig = (cen_con >> 25) & 31u;
+        const uint32_t bin_a = 2u + (qp.u_first <= 4u ? (qp.u_first < 1u ? qp.u_first : 1u) : rc_a);
+        const uint32_t bin = 2u * ncon + n14 + (shifted - census_shift_sum(cen_con, K)) + nbig * (1u + K) + (head ? bin_a : 0u);
+        // zero-run: the head, when it is not inside a run, pays 2 + its own code at the initial k (32 bits flat above that
+        // k's escape); a token of a cut run counts the run from the partition's first sample (see above)
+        const bool head_plain = head && qp.rs.first_in4 == 0u;
+        const uint32_t esc_a = 1u << ((k_a + 3u) < 24u ? (k_a + 3u) : 24u);
+        const uint32_t plain_a = 2u + (qp.u_first > esc_a ? 32u : rc_a);
+        const uint32_t nplain = (uint32_t)G::CH - qp.rs.nin4 - (head_plain ? 1u : 0u);  // samples outside runs, costed at K
+        uint32_t tokens = qp.rs.tokens;
+        if ((qp.E & 1u) != 0u && (uint32_t)qp.f0 > ca && !head && open_run <= (uint32_t)G::CH)
+            tokens = tokens + ((ca + open_run - 4u) >> 2) - (((uint32_t)qp.f0 + open_run - 4u) >> 2);
+        const uint32_t zr = shifted + nplain * (3u + K) + (head_plain ? plain_a : 0u) + tokens;
+        flush(q, sidx, quick ? rice : 0u, quick ? bin : 0u, quick ? zr : 0u, quick ? qp.rs.hasrun : 0u);
+    }
+}
+
+// One queued (chunk, order) pair of partition_quick: the plain walk over the chunk's samples (32-bit sums, the whole
+// chunk inside one partition; ZR: with the zero-run cost, runs cut at the partition's ends).
+template <class G, bool ZR = false, class Flush>
 LACX_HD void partition_slow_entry(const Smem<G>& sh, uint32_t n, uint32_t entry, Flush&& flush) {
     const uint32_t t = entry & 0xFFFu;
     const int p = (int)(entry >> 12) + 1;
@@ -1563,20 +1703,45 @@ LACX_HD void partition_slow_entry(const Smem<G>& sh, uint32_t n, uint32_t entry,
     uint32_t S = (uint32_t)sh.tabP[t] - (uint32_t)sh.tabP[s / (uint32_t)G::CH];  // sum of the partition's samples before j
     uint32_t c = a - s;                                                           // ... and their number
     uint32_t k = c == 0u ? (uint32_t)sh.xp.part.seginfo[sidx].ak : kmean32(S, c ? c : 1u);
-    uint32_t rice = 0, bin = 0;
+    uint32_t rice = 0, bin = 0, zr = 0, hasrun = 0;
     uint32_t u = sh.u[t];
+    int32_t fg = (int32_t)a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk (not yet clipped to the partition)
+    uint32_t x1 = 1, x2 = 1, x3 = 1;
+    if (ZR) {
+        x1 = peek_u<G>(sh, a + 1u, n);
+        x2 = peek_u<G>(sh, a + 2u, n);
+        x3 = peek_u<G>(sh, a + 3u, n);
+    }
 #pragma unroll
     for (int i = 0; i < G::CH; ++i) {
-        const uint32_t unext = sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
+        const uint32_t unext = ZR ? x1 : sh.u[((i + 1) & (G::CH - 1)) * G::T + t];
         const uint32_t rc = (u >> k) + 1u + k;
         rice += rc;
         bin += 2u + (u <= 4u ? (u < 1u ? u : 1u) : rc);
+        if (ZR) {
+            const uint32_t z = flag01(u == 0u);
+            fg = (fg + 1) & (int32_t)(0u - z);
+            const uint32_t ahead_g = (x1 != 0) ? 0u : ((x2 != 0) ? 1u : ((x3 != 0) ? 2u : 3u));
+            const uint32_t left = base - 1u - c;                              // samples after this one inside the partition
+            const uint32_t fp = ((uint32_t)fg < c + 1u) ? (uint32_t)fg : c + 1u;
+            const uint32_t ahead = ahead_g < left ? ahead_g : left;
+            const uint32_t in4 = z & flag01(fp + ahead >= 4u);
+            const uint32_t runend = in4 & flag01(ahead == 0u);
+            const uint32_t esc = 1u << ((k + 3u) < 24u ? (k + 3u) : 24u);
+            const uint32_t plain = 2u + ((u > esc) ? 32u : rc);
+            const uint32_t token = 5u + ((fp - 4u) >> 2);
+            zr += (plain & (in4 - 1u)) | (token & (0u - runend));
+            hasrun |= runend;
+            x1 = x2;
+            x2 = x3;
+            x3 = peek_u<G>(sh, a + (uint32_t)i + 4u, n);
+        }
         S += u;
         ++c;
         k = kmean32(S, c);
         u = unext;
     }
-    flush(sidx, rice, bin, 0u, 0u);
+    flush(sidx, rice, bin, zr, hasrun);
 }
 
 // Mode choice of one partition (ref block/encoder.cpp:495-525); returns bits, writes (mode<<5)|k.

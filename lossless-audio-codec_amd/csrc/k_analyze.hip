@@ -507,29 +507,48 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                 seg_flush(q, idx, rc, bn, 0u, 0u, false);
             };
             // (one queued chunk of partition_quick: any partition, any order per lane)
-            auto flush_entry = [&pm, ablate_flush](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t, uint32_t) {
+            auto flush_entry = [&pm, ablate_flush](uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr) {
                 if (ablate_flush) return;
                 atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][0]), rc);
                 atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][1]), bn);
+                if (zr) atomicAdd(reinterpret_cast<uint32_t*>(&pm.segacc[idx][2]), zr);
+                if (hr) atomicOr(&pm.segrun[idx], 1u);
             };
-            if (prm.zero_run && sh.best_hasrun) {
-                partition_fused<G, true>(th, sh, max_p, flush32);
-            } else if (prm.debug_skip & 32768u) {
-                partition_fused<G, false>(th, sh, max_p, flush32_nozr);  // (A/B: the plain walk)
+            const bool with_zr = prm.zero_run && sh.best_hasrun;  // (block-uniform)
+            if (prm.debug_skip & 32768u) {  // (A/B: the plain walk over every sample and order)
+                if (with_zr) partition_fused<G, true>(th, sh, max_p, flush32);
+                else partition_fused<G, false>(th, sh, max_p, flush32_nozr);
             } else {
                 // no sample walk where the Rice parameter is provably constant over the chunk; the other (chunk, order)
                 // pairs are queued and walked densely packed
                 // (per wave: no workgroup barrier, no atomic -- a wave's queue is filled and drained by the wave itself)
                 uint16_t* wq = &pm.queue[(tid >> 6) * 64 * G::MAXP];
                 uint32_t queued = 0;  // wave-uniform
-                partition_quick<G>(th, sh, max_p, flush32_nozr, [&](uint32_t entry, bool ambiguous) {
+                auto enqueue = [&](uint32_t entry, bool ambiguous) {
                     const unsigned long long m = __ballot(ambiguous);
                     if (ambiguous) wq[queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)entry;
                     queued += (uint32_t)__popcll(m);
-                });
+                };
+                asm volatile("" : "+v"(th.tid));  // (nothing derived from the thread index lives on from the phases before)
+                if (!with_zr) {
+                    partition_quick<G>(th, sh, max_p, flush32_nozr, enqueue);
+                } else {
+                    // With zero-run costs: where most of a wave's pairs would need the walk anyway (a residual whose mean
+                    // sits on a parameter boundary) the walk over all orders at once is cheaper than classifying first:
+                    // the wave decides for itself (any mix of the two gives the same sums).
+                    QuickPrep<G> qp;
+                    partition_quick_prepare<G>(th, sh, max_p, qp);
+                    uint32_t pairs = 0;  // wave-uniform
+                    for (int q = 0; q < max_p; ++q) pairs += (uint32_t)__popcll(__ballot((qp.amb >> q) & 1u));
+                    if (pairs > kQuickMaxPairs) partition_fused<G, true>(th, sh, max_p, flush32);
+                    else partition_quick_costs<G>(th, sh, max_p, qp, flush32, enqueue);
+                }
                 STAMP(7);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS stores, before it reads them back
-                for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) partition_slow_entry<G>(sh, n, wq[e], flush_entry);
+                for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) {
+                    if (with_zr) partition_slow_entry<G, true>(sh, n, wq[e], flush_entry);
+                    else partition_slow_entry<G, false>(sh, n, wq[e], flush_entry);
+                }
                 STAMP(9);
             }
         } else {

@@ -201,16 +201,32 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
             flush(idx, rc, bn, zr, hr);
         };
         const bool fused = pnarrow && !(force_wide & 2) && partitions_chunk_aligned<G>(n, max_p);
-        const bool quick = fused && !(zero_run && sh.best_hasrun) && !(force_wide & 8);
+        const bool quick = fused && !(force_wide & 8);
+        const bool with_zr = zero_run && sh.best_hasrun;
         pm.qcount = 0;
         if (getenv("LACX_SIM_QSTATS")) fprintf(stderr, "partition: n=%u narrow %d hasrun %d fused %d quick %d total_u %llu\n", n, (int)pnarrow, (int)sh.best_hasrun, (int)fused, (int)quick, (unsigned long long)sh.tabP[G::T]);
-        for (int t = 0; t < G::T; ++t) {
-            if (quick) {  // the kernel's default: no sample walk where the Rice parameter is constant over the chunk
-                partition_quick<G>(th[t], sh, max_p, flushq, [&pm](uint32_t entry, bool ambiguous) { if (ambiguous) pm.queue[pm.qcount++] = (uint16_t)entry; });
+        auto enqueue = [&pm](uint32_t entry, bool ambiguous) { if (ambiguous) pm.queue[pm.qcount++] = (uint16_t)entry; };
+        for (int w0 = 0; quick && w0 < G::T; w0 += 64) {
+            // the kernel's default: no sample walk where the Rice parameter is constant over the chunk -- wave by wave; with
+            // zero-run costs a wave with too many ambiguous pairs walks all orders at once instead
+            if (!with_zr) {
+                for (int t = w0; t < w0 + 64 && t < G::T; ++t) partition_quick<G>(th[t], sh, max_p, flushq, enqueue);
                 continue;
             }
+            std::vector<QuickPrep<G>> qp(64);
+            uint32_t pairs = 0;
+            for (int t = w0; t < w0 + 64 && t < G::T; ++t) {
+                partition_quick_prepare<G>(th[t], sh, max_p, qp[t - w0]);
+                pairs += (uint32_t)__builtin_popcount(qp[t - w0].amb);
+            }
+            for (int t = w0; t < w0 + 64 && t < G::T; ++t) {
+                if (pairs > kQuickMaxPairs && !(force_wide & 64)) partition_fused<G, true>(th[t], sh, max_p, flushq);
+                else partition_quick_costs<G>(th[t], sh, max_p, qp[t - w0], flushq, enqueue);
+            }
+        }
+        for (int t = 0; !quick && t < G::T; ++t) {
             if (fused) {
-                if (zero_run && sh.best_hasrun) partition_fused<G, true>(th[t], sh, max_p, flushq);
+                if (with_zr) partition_fused<G, true>(th[t], sh, max_p, flushq);
                 else partition_fused<G, false>(th[t], sh, max_p, flushq);
                 continue;
             }
@@ -218,7 +234,10 @@ int run_sim(const int32_t* x, uint32_t n, int zero_run, int partitioning, int fo
                 if (pnarrow) partition_pass<G, true>(th[t], sh, p, flush); else partition_pass<G, false>(th[t], sh, p, flush);
             }
         }
-        for (uint32_t e = 0; quick && e < pm.qcount; ++e) partition_slow_entry<G>(sh, n, pm.queue[e], flush);
+        for (uint32_t e = 0; quick && e < pm.qcount; ++e) {
+            if (with_zr) partition_slow_entry<G, true>(sh, n, pm.queue[e], flush);
+            else partition_slow_entry<G, false>(sh, n, pm.queue[e], flush);
+        }
         if (quick && getenv("LACX_SIM_QSTATS")) fprintf(stderr, "quick: n=%u queued %u of %u\n", n, pm.qcount, (n / (uint32_t)G::CH) * (uint32_t)max_p);
         for (int p = 1; p <= max_p; ++p) {
             pm.pbits[p] = 0;
@@ -337,7 +356,7 @@ int sim_block_encode(const int32_t* x, uint32_t n, int zero_run, int partitionin
 // force_wide bit 0: run the 64-bit arithmetic variants even where the 32-bit fast path would be taken;
 // bit 1: use the per-order partition passes even where the fused pass applies; bit 2: no candidate pruning;
 // bit 3: the fused walk instead of partition_quick; bit 4: no phase_b_quick; bit 5: check every phase_b_quick result
-// against the walk
+// against the walk; bit 6: partition_quick for every wave, whatever its count of ambiguous pairs
 int sim_block_plan(const int32_t* x, uint32_t n, int zero_run, int partitioning, int geo, int force_wide,
                    ChannelPlan* out) {
     if (geo == 0) return run_sim<Geo<16, 1024>>(x, n, zero_run, partitioning, force_wide, out);

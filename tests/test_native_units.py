@@ -74,7 +74,7 @@ def test_simulated_kernel_plans_match_oracle(pkg, oracle, sim, kind):
     cases = [(left[:16384], 0), (s[:16384], 0), (m[16384:], 0), (left[100:356], 1), (s[5000:5256], 0),
              (right[3:4100], 0), (left[9:40], 0), (m[:1], 0), (s[:13], 0), (left[:13312], 0)]
     for i, (x, geo) in enumerate(cases):
-        for wide in (0, 1, 2, 8, 16, 32, 33):
+        for wide in (0, 1, 2, 8, 16, 32, 33, 64):
             _check(sim, oracle, x, geo, True, True, wide)
     _check(sim, oracle, left[:16384], 0, False, True, 0)
     _check(sim, oracle, left[:16384], 0, True, False, 0)
@@ -156,7 +156,7 @@ def test_pruning_bound_on_zero_run_structures(pkg, oracle, sim):
             pos += gap
         blocks.append(x)
     for x in blocks:
-        for wide in (0, 4, 32):
+        for wide in (0, 4, 32, 64):
             _check(sim, oracle, x, 0, True, True, wide)
     _check(sim, oracle, np.zeros(256, np.int32), 1, True, True, 0)
 
