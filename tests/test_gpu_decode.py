@@ -174,6 +174,87 @@ def test_damaged_streams_are_refused(gpu):
             assert "decode-error" in str(err)
 
 
+class _Bits:
+    """MSB-first bit writer (the layout of ref src/codec/bitstream/bit_writer.cpp), for hand-made channel blocks."""
+
+    def __init__(self):
+        self.v, self.n = 0, 0
+
+    def put(self, value, bits):
+        assert 0 <= value < (1 << bits) or bits == 0
+        self.v = (self.v << bits) | value
+        self.n += bits
+
+    def rice(self, u, k):
+        self.put((1 << (u >> k)) - 1, u >> k)  # unary quotient: ones ...
+        self.put(0, 1)                         # ... and their terminator
+        self.put(u & ((1 << k) - 1), k)
+
+    def bytes(self):
+        pad = (-self.n) % 8
+        return ((self.v << pad)).to_bytes((self.n + pad) // 8, "big")
+
+
+def _zigzag(x):
+    return (x << 1) ^ (x >> 63)
+
+
+def test_foreign_streams_high_lpc_orders_and_escapes(gpu, oracle):
+    """Streams no test encoder writes but the format allows (ref block/decoder.cpp:64-520): LPC orders 13..32 (taps beyond
+    the register window come from the history ring in LDS), a static-Rice partition, and zero-run mode's 32-bit escape
+    with large values -- channel blocks made by hand with a bit writer, the device decoder against the oracle's (itself
+    pinned against the reference's)."""
+    rng = np.random.default_rng(8)
+    n = 1500
+    for order in (13, 14, 31, 32):
+        coefs = [int(c) for c in rng.integers(-900, 901, size=order)]  # sum |c| < 2^15: the synthesis stays small
+        res = [int(r) for r in rng.integers(-300, 301, size=n)]
+        k = 6
+        w = _Bits()
+        w.put(2, 8)               # type: LPC
+        w.put(order, 8)
+        for c in coefs:
+            w.put(c & 0xFFFF, 16)
+        w.put((3 << 5) | 0, 8)    # control: no partitioning, mode of the block = static Rice
+        w.put(3, 2)               # partition table, one entry: mode, k
+        w.put(k, 5)
+        for r in res:
+            w.rice(_zigzag(r), k)
+        pay = w.bytes()
+        lac = gpu.lacx.assemble(48000, 24, 0, 1, [(pay, np.array([[n, len(pay)]], dtype=np.uint32))])
+        lo, ro, _ = oracle.decode(lac)
+        l2, r2, info, _ = gpu.lacx.decode(lac)
+        assert ro is None and r2 is None and info.frames == n
+        assert np.array_equal(l2, lo), order
+        assert np.abs(lo).max() > 300  # the predictor did something
+    # zero-run mode, every sample as the 32-bit escape (tag 2 + 32 bits), values up to the 24-bit range
+    vals = [int(v) for v in rng.integers(-(1 << 23), 1 << 23, size=n)]
+    vals[:4] = [(1 << 23) - 1, -(1 << 23), 0, 1]
+
+    def escape_block(values):
+        w = _Bits()
+        w.put(0, 8)               # type: fixed predictor ...
+        w.put(0, 8)               # ... of order 0: the residual is the sample
+        w.put((1 << 5) | 0, 8)    # control: no partitioning, zero-run mode
+        w.put(1, 2)
+        w.put(9, 5)
+        for v in values:
+            w.put(2, 2)
+            w.put(_zigzag(v) & 0xFFFFFFFF, 32)
+        return w.bytes()
+
+    pay = escape_block(vals)
+    lac = gpu.lacx.assemble(48000, 24, 0, 1, [(pay, np.array([[n, len(pay)]], dtype=np.uint32))])
+    lo, _, _ = oracle.decode(lac)
+    l2, _, _, _ = gpu.lacx.decode(lac)
+    assert np.array_equal(l2, lo) and np.array_equal(l2, np.array(vals, dtype=np.int32))
+    # a magnitude the encoder's domain cannot produce (>= 2^30) is refused, not decoded differently from the reference
+    pay = escape_block(vals[:10] + [1 << 29] + vals[11:])
+    lac = gpu.lacx.assemble(48000, 24, 0, 1, [(pay, np.array([[n, len(pay)]], dtype=np.uint32))])
+    with pytest.raises(RuntimeError, match=r"decode-error\] block=0"):
+        gpu.lacx.decode(lac)
+
+
 def test_legacy_version_2_container(gpu):
     """Version 2 of the container has no compressed block sizes (ref lac/decoder.cpp:100-104, 209-219): the same block
     payloads back to back behind a table of frame counts.  Rebuilt here from a version-3 stream; one lane walks it."""
