@@ -279,6 +279,50 @@ __device__ uint32_t decode_channel_block(BitIn& r, uint32_t n, int32_t* __restri
             ++part;
             adapt_reset(a);
         }
+        // The plain trip: every lane of the wave that is still decoding sits in a partition whose tokens are bare Rice
+        // codes -- static Rice, or adaptive Rice of a partitioned block (stateless: prefix mean only) -- no run in
+        // progress, at most twelve taps, and the unary part ends among the bits at hand.  Most of a music stream is that
+        // (this encoder picks static Rice for nearly every partition of ordinary material), and the trip then is a third
+        // of the general one below: no tag, no mode selects, no windows.  Wave-uniform choice per trip.
+        {
+            const bool plain = zeros_left == 0u && (mode == kModeStatic || (mode == 0u && stateless)) && !(type == 2u && order > 12);
+            bool lean = __ballot(!plain) == 0ull;
+            uint32_t ones = 0;
+            if (lean) {
+                refill(r);
+                const unsigned long long inv = ~r.buf;  // the invalid low bits of buf are zero: they read as terminators
+                ones = inv ? (uint32_t)__clzll((long long)inv) : 64u;
+                lean = __ballot(ones >= r.have) == 0ull;
+            }
+            if (lean) {
+                consume(r, ones + 1u);
+                uint32_t bad = ones > (0xFFFFFFFFu >> k) ? 3u : 0u;
+                if (r.have < k) refill(r);
+                const uint32_t u = (ones << k) | take(r, k);
+                if (overrun(r)) bad = 3u;
+                if (!bad && (u >> 30)) bad = 9u;
+                long long acc = 0;
+#pragma unroll
+                for (int t = 0; t < 12; ++t) acc += (long long)cw[t] * (long long)hw[t];
+                const long long s = (long long)unzigzag(u) + (i >= warm ? (acc >> pshift) : 0ll);
+                if ((long long)(int32_t)s != s && !bad) bad = 5u;
+                if (bad) {
+                    st = bad;
+                    break;
+                }
+                if (mode == 0u) {  // stateless adaptation: the prefix mean of the partition (ref block/encoder.cpp:72-77)
+                    a.sum += u;
+                    a.count += 1u;
+                    const uint32_t km = (a.sum >> 31) == 0ull ? kmean32((uint32_t)a.sum, a.count) : kmean(a.sum, a.count);
+                    k = km > 31u ? 31u : km;
+                }
+                out[i] = (int32_t)s;
+#pragma unroll
+                for (int t = 11; t > 0; --t) hw[t] = hw[t - 1];
+                hw[0] = (int32_t)s;
+                continue;
+            }
+        }
         // One token, whatever the grammar: [2-bit tag] [unary quotient] [remainder / sign / 32-bit escape], each part
         // present or not, chosen by selects -- the trip has the same few branches for every mode (refills, the long
         // unary form, the stateful adaptation, the error exit).  A zero run in progress yields its zeros one per trip.
