@@ -541,7 +541,11 @@ int lacx_block_encode(lacx_encoder* e, const int32_t* pcm, uint32_t n, uint8_t**
     return LACX_OK;
 }
 
-int lacx_debug_stamps(unsigned long long* out32) { return debug_read_stamps(out32); }
+int lacx_debug_stamps(unsigned long long* out32) {
+    const int rc = debug_read_stamps(out32);
+    if (rc) (void)debug_read_offset_stamps(out32 + 33);  // k_offsets: start, loads back, scan barrier, stores issued (100 MHz ticks)
+    return rc;
+}
 
 int lacx_debug_emit_workers(lacx_encoder* e) { return e ? (int)pool_of(e).threads() : -1; }
 

@@ -22,6 +22,12 @@ namespace lacx {
 // prefix -> block_off[0..nb] (byte offset of the block in the result buffer), and the container's block table entries
 // (frames, bytes).  In a set of several streams every stream's payload starts at its own region (StreamDesc::out_base):
 // stream_pre[s] receives the prefix at the stream's first block and the offsets are re-based per stream.
+#ifdef LACX_STAMPS
+__device__ unsigned long long g_off_stamps[8];  // (diagnostic: 100 MHz realtime stamps of thread 0 of k_offsets)
+#define OFF_STAMP(i) do { if (threadIdx.x == 0) g_off_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OFF_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_offsets(BatchRef br, const BlockPlan* __restrict__ bplans,
                                                    const ChannelPlan* __restrict__ plans,
                                                    unsigned long long* __restrict__ block_off,
@@ -30,6 +36,7 @@ __global__ __launch_bounds__(1024) void k_offsets(BatchRef br, const BlockPlan* 
                                                    unsigned long long* __restrict__ stream_pre) {
     __shared__ unsigned long long s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    OFF_STAMP(0);
     const uint32_t nb = br.total_blocks;
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = (uint32_t)tid * per;
@@ -52,9 +59,11 @@ __global__ __launch_bounds__(1024) void k_offsets(BatchRef br, const BlockPlan* 
         if (b - b0 < kKeep) kept[b - b0] = bytes;
         sum += bytes;
     }
+    OFF_STAMP(1);  // (the sum depends on every load: they are back)
     const unsigned long long inc = wave_scan_add_u64(sum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
+    OFF_STAMP(2);
     unsigned long long base = base_ptr ? *base_ptr : 0ull;  // bytes of the chunks before this one
     for (int w = 0; w < wave; ++w) base += s_w[w];
     unsigned long long run = base + inc - sum;
@@ -70,6 +79,7 @@ __global__ __launch_bounds__(1024) void k_offsets(BatchRef br, const BlockPlan* 
         run += bytes;
     }
     if (tid == 1023) block_off[nb] = base + inc;
+    OFF_STAMP(3);
     if (br.table != nullptr) {  // uniform
         __syncthreads();  // (block_off is global memory written by this workgroup: visible to it after the barrier)
         for (uint32_t sidx = (uint32_t)tid; sidx < br.nstreams; sidx += 1024u) stream_pre[sidx] = block_off[br.table[sidx].first_block];
@@ -411,6 +421,15 @@ __global__ __launch_bounds__(256) void k_gather(GatherList g) {
 hipError_t set_kernel_attrs_emit() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emit<GFull>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)sizeof(EmitMem<GFull>));
+}
+
+int debug_read_offset_stamps(unsigned long long* out8) {  // (diagnostic builds only)
+#ifdef LACX_STAMPS
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_off_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 1 : 0;
+#else
+    (void)out8;
+    return 0;
+#endif
 }
 
 hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out,

@@ -144,6 +144,7 @@ hipError_t launch_wide_block(const int32_t* d_x, uint32_t n, int zero_run, int p
 size_t analyze_smem_bytes_full();
 // Diagnostic builds (-DLACX_STAMPS) only: per-phase shader-cycle sums over all waves; returns 0 otherwise.
 int debug_read_stamps(unsigned long long* out32);
+int debug_read_offset_stamps(unsigned long long* out8);  // k_offsets, diagnostic builds (k_emit.hip)
 size_t analyze_smem_bytes_probe();
 
 }  // namespace lacx
