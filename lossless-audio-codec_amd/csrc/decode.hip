@@ -45,32 +45,34 @@ constexpr size_t kDecBytesPerCol = 256 * 4 + 32 * 4 + 32 * 2;
 
 // MSB-first bit reader over a byte stream in global memory (ref src/codec/bitstream/bit_reader.hpp).  A lane's stream is
 // latency-bound -- every token's position depends on the one before -- so the reader keeps the next bits in a 64-bit
-// register (buf: `have` valid bits from r.pos on, left-aligned, zeros below) and fetches the stream as 64-bit words one
-// word AHEAD of the one it is consuming (nxt, byte-swapped only when it becomes current, so that nothing waits for the
-// load before it is needed).  Positions are 32-bit, relative to the block (a block's bitstream is far below 2^32 bits).
+// register (buf: `have` valid bits from r.pos on, left-aligned, zeros below) and fetches the stream as 32-bit words one
+// word AHEAD of the one it appends (nxt, byte-swapped only when it is appended, so that nothing waits for the load
+// before it is needed); one word per top-up keeps the top-up at eight instructions.  Positions are 32-bit, relative to
+// the block (a block's bitstream is far below 2^32 bits).
 // Bounds are not checked read by read: a read past the end of the block yields bits of the next block or of the
 // kDecodeTailPad zero bytes the host appends to the payload, and the caller compares r.pos with r.nbits once per trip
 // (overrun()); every loop whose length the stream controls (the coefficient list, a long unary run, the partition
 // table) checks BEFORE it reads.  Worst overshoot of one trip from r.pos <= r.nbits: 2 tag bits + 64 unary bits at hand
-// + 32 remainder bits = 13 bytes, plus the reader's two 8-byte words of look-ahead: 37 bytes < kDecodeTailPad.
+// + 32 remainder bits = 13 bytes, plus the reader's 64 buffered bits and one 4-byte word of look-ahead: 25 bytes < kDecodeTailPad.
 struct BitIn {
     const uint8_t* p;
-    uint32_t nbits, pos, have, widx;  // widx: index of cur
-    unsigned long long buf, cur, nxt;  // cur: the word that holds bit r.pos + have; nxt: the word after it, still raw
+    uint32_t nbits, pos, have, widx;  // widx: index of the 32-bit word held (still raw) in nxt = the word of bit pos + have
+    unsigned long long buf;
+    uint32_t nxt;
 };
 
-__device__ __forceinline__ unsigned long long load_word(const uint8_t* p, uint32_t idx) {
-    unsigned long long w;
-    __builtin_memcpy(&w, p + 8ull * idx, 8);
+__device__ __forceinline__ uint32_t load_word(const uint8_t* p, uint32_t idx) {
+    uint32_t w;
+    __builtin_memcpy(&w, p + 4ull * idx, 4);
     return w;
 }
 __device__ __forceinline__ void reader_seek(BitIn& r, uint32_t bitpos) {
+    const uint32_t o = bitpos & 31u;
     r.pos = bitpos;
-    r.have = 0;
-    r.buf = 0;
-    r.widx = bitpos >> 6;
-    r.cur = __builtin_bswap64(load_word(r.p, r.widx));
-    r.nxt = load_word(r.p, r.widx + 1u);
+    r.widx = (bitpos >> 5) + 1u;
+    r.buf = ((unsigned long long)__builtin_bswap32(load_word(r.p, r.widx - 1u)) << 32) << o;  // the word's bits from bitpos on
+    r.have = 32u - o;
+    r.nxt = load_word(r.p, r.widx);
 }
 __device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, uint32_t nbits) {
     r.p = p;
@@ -78,20 +80,15 @@ __device__ __forceinline__ void reader_init(BitIn& r, const uint8_t* p, uint32_t
     reader_seek(r, 0);
 }
 __device__ __forceinline__ bool overrun(const BitIn& r) { return r.pos > r.nbits; }
-// one step of topping the register up: the rest of the current word, or as much of it as fits
+// one step of topping the register up (have <= 32): the next 32-bit word of the stream goes in behind the bits at hand,
+// the word after it is fetched (the low bits of buf beyond `have` are zero: invariant)
 __device__ __forceinline__ void refill_step(BitIn& r) {
-    const uint32_t o = (r.pos + r.have) & 63u;  // offset of the first missing bit inside cur
-    const uint32_t room = 64u - r.have, left = 64u - o;
-    const uint32_t take = room < left ? room : left;
-    r.buf |= (r.cur << o) >> r.have;  // have < 64 here; the low bits of buf beyond `have` are zero (invariant)
-    r.have += take;
-    if (take == left) {  // cur is used up: move on, fetch one word further ahead
-        r.cur = __builtin_bswap64(r.nxt);
-        ++r.widx;
-        r.nxt = load_word(r.p, r.widx + 1u);
-    }
+    r.buf |= (unsigned long long)__builtin_bswap32(r.nxt) << (32u - r.have);
+    r.have += 32u;
+    ++r.widx;
+    r.nxt = load_word(r.p, r.widx);
 }
-// afterwards the register holds at least 33 valid bits (two steps at most)
+// afterwards the register holds at least 33 valid bits (a second step only when it was empty)
 __device__ __forceinline__ void refill(BitIn& r) {
     if (r.have <= 32u) {
         refill_step(r);
