@@ -109,6 +109,7 @@ void free_workspace(lacx_encoder* e) {
     if (e->zero_region) (void)hipFree(e->zero_region);  // size_rec, ready_rec, tspan, emitted, packed, err_flag
     e->zero_region = nullptr;
     e->d_tspan = nullptr;
+    e->d_work_ctr = nullptr;
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -137,7 +138,8 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             const size_t ranges = items / kPackerRangeItems + 2;  // packer progress (copy-engine drain)
             const size_t bytes = items * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) +
                                  sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 4) +
-                                 ranges * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16;
+                                 ranges * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16 +
+                                 sizeof(uint32_t) * 8 * (kMaxChunks + 1);  // work counters of the persistent analysis
             e->zero_bytes = (bytes + 15) & ~(size_t)15;
             HIP_TRY(e, hipMalloc((void**)&e->zero_region, e->zero_bytes), "hipMalloc(zeroed region)");
             uint8_t* p = e->zero_region;
@@ -157,6 +159,9 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             e->d_range_end = reinterpret_cast<unsigned long long*>(p);
             p += ranges * sizeof(unsigned long long);
             e->d_range_cnt = reinterpret_cast<uint32_t*>(p);
+            p += ranges * sizeof(uint32_t);
+            p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 3) & ~(uintptr_t)3);
+            e->d_work_ctr = reinterpret_cast<uint32_t*>(p);
         }
         e->ws_blocks = nblocks;
     }

@@ -178,6 +178,7 @@ ChunkCtx chunk_ctx(lacx_encoder* e, const int32_t* d_left, const int32_t* d_righ
     x.w.err_flag = e->ws.err_flag + c;
     x.w.t_first = e->d_tspan + c;
     x.w.t_last = e->d_tspan + kMaxChunks + c;
+    x.w.work_ctr = e->d_work_ctr + 8 * c;
     return x;
 }
 
@@ -348,12 +349,18 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         (void)cr;
         (void)prm;
         LaunchSet ls = cx.set(fuse_items, emit_cap);
-        HIP_TRY(e, launch_analysis(bind(ls), w, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
+        // persistent analysis workgroups only for a shard that is one chunk: with several, the next chunk's ingest /
+        // Levinson / probe kernels are meant to run beside this chunk's analysis, which persistent workgroups would not let in
+        DeviceWorkspace wl = w;
+        if (chunks.size() > 1) wl.work_ctr = nullptr;
+        HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
         if (c == 0 && fuse_items && !std::getenv("LACX_NO_PACKER")) {
             // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first
             // chunk's ingest / Levinson / probe kernels are done (ev[0][2] is recorded right in front of the whole-block
             // kernel), so its bounded waits only ever cover the progress of the analysis itself, however long the shard.
-            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][2], 0), "stream wait");
+            // (With persistent analysis workgroups it has to be resident before they are: it then starts in front of the
+            // ingest kernel -- ev[0][0], behind the call's memset -- and holds its CUs through the front kernels.)
+            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][analysis_is_persistent(wl) ? 0 : 2], 0), "stream wait");
             // (the packer walks the whole shard: one stream whose indices start at 0)
             AnalyzeParams shard_prm = make_params(e, frames, channels, e->cfg.stereo_mode, e->cfg.bit_depth, layout);
             shard_prm.stream_base = 0;
@@ -767,6 +774,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     DeviceWorkspace w = e->ws;
     w.t_first = e->d_tspan;
     w.t_last = e->d_tspan + kMaxChunks;
+    w.work_ctr = e->d_work_ctr;
     FuseArgs fa;
     fa.slots = e->ws.slots;
     fa.slot_stride = e->ws.slot_stride;
@@ -778,7 +786,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
         HIP_TRY(e, launch_analysis(ls, w, s, e->ev[0], &fa, nullptr), "kernel launch");
         const bool packer = !std::getenv("LACX_NO_PACKER");
         if (packer) {
-            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][2], 0), "stream wait");
+            HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][analysis_is_persistent(w) ? 0 : 2], 0), "stream wait");
             HIP_TRY(e, launch_stream_out(ls, e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
         }

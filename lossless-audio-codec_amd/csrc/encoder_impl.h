@@ -100,6 +100,7 @@ struct lacx_encoder {
     uint32_t* h_emitted = nullptr; // pinned copy of ws.emitted (statistics of the fused emit)
     uint32_t h_emitted_cap = 0;
     unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: ~first-start / last-end device clock of k_analyze<16,1024>
+    uint32_t* d_work_ctr = nullptr;  // zeroed per call: work counters of the persistent analysis, 8 per pipeline chunk
     uint8_t* zero_region = nullptr;         // one allocation for everything that is zeroed before every call
     size_t zero_bytes = 0;
     unsigned long long* h_tspan = nullptr;  // pinned copy

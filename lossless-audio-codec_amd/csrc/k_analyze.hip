@@ -42,11 +42,17 @@ __device__ unsigned long long g_stamp_acc[40];
 // Every wait of the packer is bounded; when it gives up, or for anything it did not move, k_pack / k_emit finish the
 // job after the analysis (they always run), so no dispatch order or co-residency is assumed for correctness.
 // ---------------------------------------------------------------------------------------------
+// A slot whose bitstream has been stored but not announced yet (persistent workgroups).
+struct PendingSlot {
+    long long idx = -1;
+    bool done = false, silent = false;
+};
+
 // idx: stream index of this channel block; flag_byte: the block's LR/MS flag byte precedes this channel block.
 template <class G>
 __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const AnalyzeParams& prm, const FuseArgs& fa,
                                            const long long idx, const bool flag_byte, const uint32_t flag_value,
-                                           const int tid STAMP_PARAMS) {
+                                           const int tid, PendingSlot* defer STAMP_PARAMS) {
     const uint32_t n = th.n;
     // Optimisation barrier on the thread's coordinates: without it the compiler computes the LDS addresses of the emit
     // phases at kernel entry and keeps them alive (spilled to scratch) through the whole analysis.
@@ -76,7 +82,15 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
                             (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride STAMP_ARGS);
     }
     // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
-    // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1)
+    // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1).  A persistent
+    // workgroup does not wait here: it announces the slot behind the barrier that ends the staging of its next slot
+    // (publish_pending), when the stores have long drained.
+    if (defer) {
+        defer->idx = idx;
+        defer->done = done;
+        defer->silent = (prm.debug_skip & 8192u) != 0u;
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -84,6 +98,16 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
         // test hook (bit 13): the slot is filled but never announced, so the packer gives up and k_pack takes over
         if (!(prm.debug_skip & 8192u)) rec_store(&fa.ready_rec[idx], done ? 1ull : 2ull);
     }
+}
+
+// The announcement of a slot whose stores every wave of the workgroup has drained (s_waitcnt vmcnt(0)) before the barrier
+// the caller has just passed.
+__device__ __forceinline__ void publish_pending(const FuseArgs& fa, PendingSlot& pend, int tid) {
+    if (pend.idx >= 0 && tid == 0) {
+        if (pend.done) fa.emitted[pend.idx] = 2u;
+        if (!pend.silent) rec_store(&fa.ready_rec[pend.idx], pend.done ? 1ull : 2ull);
+    }
+    pend.idx = -1;
 }
 
 // Candidate scoring (ref block/encoder.cpp:337-359) by the 64 lanes of one wave; same result as score_candidate() of
@@ -153,7 +177,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                                              const SlotSrc& src, int64_t start, const LpcSet* __restrict__ lpc_slot,
                                              ChannelPlan* __restrict__ plan_out, const int tid, const FuseArgs& fuse,
                                              const long long fuse_idx, const bool fuse_flag_byte,
-                                             const uint32_t fuse_flag_value) {
+                                             const uint32_t fuse_flag_value, PendingSlot* pend) {
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
     const uint32_t n = n_in;
 #ifdef LACX_STAMPS
@@ -178,7 +202,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         sh.best_cand = -1;
         sh.tabUZ[G::T] = sh.tabUZ[G::T + 1] = 0;  // "not a zero" past the slot (phase_b_quick)
     }
+    if (pend && pend->idx >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (uniform) the previous slot's stores
     __syncthreads();
+    if (pend) publish_pending(fuse, *pend, tid);
     STAMP(0);
 
     // ---- pass 1: the pruning bound of every candidate ------------------------------------------------------------
@@ -586,7 +612,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
     STAMP(21);
     if constexpr (G::T == 1024) {
-        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid STAMP_ARGS);  // uniform
+        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid, pend STAMP_ARGS);  // uniform
     }
     STAMP(23);
 #if defined(LACX_STAMPS) && LACX_STAMPS == 1
@@ -609,75 +635,112 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans,
                                                   unsigned long long* __restrict__ t_first,
-                                                  unsigned long long* __restrict__ t_last, FuseArgs fuse) {
+                                                  unsigned long long* __restrict__ t_last, FuseArgs fuse,
+                                                  uint32_t* __restrict__ work_ctr, uint32_t total_wg) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ uint32_t s_next;
     const int tid = threadIdx.x;
     // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
     if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
-    // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
-    // should be one that has work.  Whole-block class: the stream's workgroup w analyses the (w % per)-th needed slot of
-    // its block w / per (per = the stream's channels; the streams of a set follow each other in the grid).  Probe class:
-    // 12 slots per block, skipped unless the block is uncertain.  which_base != 0: the two extra workgroups of ONE block
-    // (global block one_block) whose four channels are all needed.
-    uint32_t blk;  // global block of the launch set
-    int slot = -1;
-    int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
-    uint32_t needed_slots = 0;
-    StreamDesc sd;
-    if (probe_class) {
-        blk = blockIdx.x / 12u;
-        sd = stream_of_block_uniform(br, blk);
-        const int s = 4 + (int)(blockIdx.x % 12u);
-        if ((need[blk] >> s) & 1u) slot = s;
-    } else {
-        uint32_t wsel;
-        if (which_base) {
-            blk = one_block;
+    // Persistent form (work_ctr != nullptr; whole-block class only): one workgroup per CU takes virtual workgroup ids from
+    // a counter until none is left, instead of one launched workgroup per slot.  A 1024-thread workgroup that owns a
+    // whole CU costs a turnaround when it retires (all sixteen waves gone, LDS released, sixteen new waves set up), and
+    // its last act was waiting for its slot stores to drain before announcing the slot; the persistent workgroup goes
+    // straight on to staging its next slot and announces the previous one behind that staging's barrier.  ONE counter
+    // for the whole chip: with a counter per XCD (to keep the two slots of a block on one XCD, as the launched grid
+    // does) the XCDs that lend a CU to the streaming packer finish 3 % later than the others, which costs more than the
+    // sibling's L2 hit is worth.  Dynamic, so the workgroups that find no free CU while the packer holds its three simply
+    // find no work left when they start.
+    const bool persistent = work_ctr != nullptr;  // (uniform)
+    uint32_t v = blockIdx.x;  // virtual workgroup id
+    PendingSlot pend;
+    if (persistent) {
+        if (tid == 0) s_next = atomicAdd(work_ctr, 1u);
+        __syncthreads();
+        v = s_next;
+    }
+    for (;;) {
+        if (persistent && v >= total_wg) break;
+        // Dense grids: consecutive workgroups are dealt round-robin to the 8 XCDs, so every launched workgroup
+        // should be one that has work.  Whole-block class: the stream's workgroup w analyses the (w % per)-th needed slot
+        // of its block w / per (per = the stream's channels; the streams of a set follow each other in the grid).  Probe
+        // class: 12 slots per block, skipped unless the block is uncertain.  which_base != 0: the two extra workgroups of
+        // ONE block (global block one_block) whose four channels are all needed.
+        uint32_t blk;  // global block of the launch set
+        int slot = -1;
+        int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
+        uint32_t needed_slots = 0;
+        StreamDesc sd;
+        if (probe_class) {
+            blk = v / 12u;
             sd = stream_of_block_uniform(br, blk);
-            wsel = blockIdx.x;
+            const int s = 4 + (int)(v % 12u);
+            if ((need[blk] >> s) & 1u) slot = s;
         } else {
-            sd = stream_of_workgroup(br, blockIdx.x);
-            const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
-            uint32_t lblk;
-            xcd_slot(blockIdx.x - sd.first_wg, per, (sd.prm.debug_skip & 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
-            blk = sd.first_block + lblk;
-        }
-        int which = (int)wsel + which_base;
-        which_in_block = which;
-        uint32_t m = need[blk] & 0xFu;
-        needed_slots = (uint32_t)__popc(m);
-        while (m) {
-            const int s = __ffs((int)m) - 1;
-            if (which == 0) {
-                slot = s;
-                break;
+            uint32_t wsel;
+            if (which_base) {
+                blk = one_block;
+                sd = stream_of_block_uniform(br, blk);
+                wsel = v;
+            } else {
+                sd = stream_of_workgroup(br, v);
+                const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
+                uint32_t lblk;
+                xcd_slot(v - sd.first_wg, per, (sd.prm.debug_skip & 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
+                blk = sd.first_block + lblk;
             }
-            --which;
-            m &= m - 1u;
+            int which = (int)wsel + which_base;
+            which_in_block = which;
+            uint32_t m = need[blk] & 0xFu;
+            needed_slots = (uint32_t)__popc(m);
+            while (m) {
+                const int s = __ffs((int)m) - 1;
+                if (which == 0) {
+                    slot = s;
+                    break;
+                }
+                --which;
+                m &= m - 1u;
+            }
         }
-    }
-    if (slot < 0) return;  // uniform for the workgroup
-    const AnalyzeParams prm = sd.prm;
-    const uint32_t lblk = blk - sd.first_block;
-    const SlotGeom g = slot_geom(prm, lblk, slot);
-    const uint32_t n = g.n;
-    const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
-    const SlotSrc src = slot_src(prm, sd.left, sd.right, slot & 3);
+        if (slot >= 0) {  // uniform for the workgroup
+            const AnalyzeParams prm = sd.prm;
+            const uint32_t lblk = blk - sd.first_block;
+            const SlotGeom g = slot_geom(prm, lblk, slot);
+            const uint32_t n = g.n;
+            const size_t sidx = (size_t)blk * kSlotsPerBlock + slot;
+            const SlotSrc src = slot_src(prm, sd.left, sd.right, slot & 3);
 
-    // Fused emit: only where the block's channel pair is already final, i.e. exactly `channels` whole-block slots are
-    // needed (a small final block that is encoded both ways and compared afterwards is left to k_emit).
-    long long fuse_idx = -1;
-    bool flag_byte = false;
-    if (fuse.slots && !probe_class && !which_base) {
-        const uint32_t item = lblk * (uint32_t)prm.channels + (uint32_t)which_in_block;  // within the stream
-        fuse_idx = (long long)prm.stream_base + item;
-        flag_byte = prm.channels == 2 && prm.stereo_mode == 2 && which_in_block == 0;
-        // the host excludes a small final block that may be encoded both ways and compared afterwards (fuse_items)
-        if (item >= sd.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
+            // Fused emit: only where the block's channel pair is already final, i.e. exactly `channels` whole-block slots
+            // are needed (a small final block that is encoded both ways and compared afterwards is left to k_emit).
+            long long fuse_idx = -1;
+            bool flag_byte = false;
+            if (fuse.slots && !probe_class && !which_base) {
+                const uint32_t item = lblk * (uint32_t)prm.channels + (uint32_t)which_in_block;  // within the stream
+                fuse_idx = (long long)prm.stream_base + item;
+                flag_byte = prm.channels == 2 && prm.stereo_mode == 2 && which_in_block == 0;
+                // the host excludes a small final block that may be encoded both ways and compared afterwards (fuse_items)
+                if (item >= sd.fuse_items || needed_slots != (uint32_t)prm.channels) fuse_idx = -1;
+            }
+            // (an opaque copy of the thread index per slot: otherwise everything the analysis derives from it is invariant
+            // in the persistent loop, hoisted out of it and kept alive in scratch memory)
+            int slot_tid = tid;
+            asm volatile("" : "+v"(slot_tid));
+            analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], slot_tid, fuse, fuse_idx, flag_byte,
+                            (uint32_t)((slot & 3) >= 2 ? 1u : 0u), persistent ? &pend : nullptr);
+            if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        }
+        if (!persistent) break;
+        __syncthreads();  // every wave is done with this slot's LDS image (the emit's tile aliases the next staging area)
+        if (tid == 0) s_next = atomicAdd(work_ctr, 1u);
+        __syncthreads();
+        v = s_next;
     }
-    analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], tid, fuse, fuse_idx, flag_byte,
-                    (uint32_t)((slot & 3) >= 2 ? 1u : 0u));
-    if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (pend.idx >= 0) {  // (uniform) the last slot of a persistent workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        publish_pending(fuse, pend, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,6 +785,20 @@ hipError_t ensure_kernel_attrs() {
     return e;
 }
 
+// CUs of the current device (cached per device ordinal).
+static uint32_t compute_units() {
+    static std::mutex mu;
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256u;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return (uint32_t)cus[dev];
+}
+
 hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
                            const FuseArgs* fuse, hipEvent_t wait_before_full) {
     const FuseArgs fa = fuse ? *fuse : FuseArgs{};
@@ -752,7 +829,8 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     }
     if (any_auto) {
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, br, 1, 0u, 0,
-                           ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+                           ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
+                           (uint32_t*)nullptr, 0u);
         hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
@@ -761,8 +839,16 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_full, 0);
         if (we != hipSuccess) return we;
     }
-    hipLaunchKernelGGL(k_analyze<GFull>, dim3(total_wg), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
-                       ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa);
+    // Persistent form where the caller provides the (zeroed) work counters: one workgroup per CU.  The streaming packer
+    // is resident by then (it is started in front of the ingest kernel in this form); the two or three workgroups that
+    // find its CUs taken wait, start when the others have left, find no work and leave.
+    const bool persistent = analysis_is_persistent(ws);
+    uint32_t pgrid = compute_units();
+    if (const char* v = std::getenv("LACX_PERSISTENT_GRID")) pgrid = std::atoi(v) > 0 ? (uint32_t)std::atoi(v) : pgrid;  // tuning knob
+    const uint32_t grid = persistent ? (total_wg < pgrid ? total_wg : pgrid) : total_wg;
+    hipLaunchKernelGGL(k_analyze<GFull>, dim3(grid), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
+                       ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa, persistent ? ws.work_ctr : (uint32_t*)nullptr,
+                       total_wg);
     if (any_both) {  // the 3rd and 4th slots of such a final block: a two-workgroup launch each
         for (uint32_t i = 0; i < ls.nstreams; ++i) {
             const StreamDesc& sd = ls.streams[i];
@@ -770,7 +856,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
             if (p.channels == 2 && p.stereo_mode == 2 && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit)
                 hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0,
                                    sd.first_block + p.num_blocks - 1u, 2, ws.lpcs, ws.need_full, ws.plans,
-                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{});
+                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{}, (uint32_t*)nullptr, 0u);
         }
     }
     if (ev) (void)hipEventRecord(ev[3], stream);

@@ -1,6 +1,7 @@
 // kernels.h -- host-visible interface of the kernel translation units (k_front.hip, k_analyze.hip, k_emit.hip,
 // decode.hip, wide.hip).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 
 #include "lacx_types.h"
@@ -8,6 +9,7 @@
 namespace lacx {
 
 // Device buffers sized for `num_blocks` blocks (allocated by the API layer).
+
 struct DeviceWorkspace {
     ChannelPlan* plans = nullptr;   // [num_blocks][kSlotsPerBlock]
     BlockPlan* bplans = nullptr;    // [num_blocks]
@@ -24,6 +26,7 @@ struct DeviceWorkspace {
     // ended: its execution span without the time it queued behind other streams (null = not recorded)
     unsigned long long* t_first = nullptr;
     unsigned long long* t_last = nullptr;
+    uint32_t* work_ctr = nullptr;  // a zeroed word: the whole-block analysis runs as persistent workgroups that take their work from it
     // Emit fused into the whole-block analysis kernel (shard-wide arrays, indexed by stream index = block * channels +
     // channel; NOT advanced per pipeline chunk): one fixed-stride staging slot per channel block and a "bitstream is in
     // its slot" flag.
@@ -35,6 +38,14 @@ struct DeviceWorkspace {
     unsigned long long* ready_rec = nullptr;
     unsigned long long* stream_pre = nullptr; // [streams] k_offsets: payload prefix at every stream's first block (sets of several streams)
 };
+
+// The whole-block analysis runs as persistent workgroups (one per CU, work taken from counters) where the caller provides
+// the zeroed counters.  The streaming packer must then be resident BEFORE that kernel starts: persistent workgroups never
+// retire, and a packer that arrives after them finds no CU until the analysis is over (its workgroups are dealt to XCDs
+// and shader engines round-robin, whether or not a CU is free there).
+inline bool analysis_is_persistent(const DeviceWorkspace& ws) {
+    return ws.work_ctr != nullptr && std::getenv("LACX_NO_PERSISTENT") == nullptr;
+}
 
 // Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while
 // the analysis runs (one stream).  host_end == nullptr: off.
