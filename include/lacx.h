@@ -20,6 +20,9 @@
  *   lacx_assemble          <- the block loop + block table concat of LAC::Encoder::encode, split so that
  *                             contiguous block ranges can be encoded by different GPUs/processes
  *                                                            ref lac/encoder.cpp:252-263, 445-465
+ *   lacx_encoder_create_multi /
+ *   lacx_encode_fanout_resident <- the worker pool of LAC::Encoder::encode with devices as the workers
+ *                                                            ref lac/encoder.cpp:385-443, 445-465
  *   lacx_encode_batch_device <- one LAC::Encoder::encode per file of a corpus, as one device job
  *                                                            ref lac/encoder.cpp:215-466 (block pool :404-435)
  *   lacx_stream_parse /
@@ -54,11 +57,13 @@ typedef struct lacx_config {
     uint8_t stereo_mode;          /* 0 LR, 1 MS, 2 per-block auto (ignored for mono input) */
     uint8_t zero_run_enabled;     /* reference default: 1 */
     uint8_t partitioning_enabled; /* reference default: 1 */
-    int32_t device;               /* HIP device ordinal, -1 = current device */
+    int32_t device;               /* HIP device ordinal, -1 = current device, LACX_DEVICE_ALL = every visible device
+                                     (whole-stream calls fan the blocks out over them, see lacx_encoder_create_multi) */
     uint32_t emit_threads;        /* host emit worker threads, 0 = hardware concurrency */
     uint32_t flags;               /* LACX_FLAG_* */
 } lacx_config;
 
+#define LACX_DEVICE_ALL (-2)
 #define LACX_FLAG_HOST_EMIT 1u /* keep the bit emit on the host (north_star layout); default: device-side emit */
 
 /* Same layout as lacx::ChannelPlan (csrc/lacx_types.h). */
@@ -233,6 +238,63 @@ int lacx_encode_wav_view(lacx_encoder* enc, const uint8_t* wav, uint64_t size, c
 int lacx_assemble(const lacx_config* cfg, int channels, uint32_t nshards, const uint8_t* const* payloads,
                   const uint64_t* payload_sizes, const uint32_t* const* tables, const uint32_t* nblocks,
                   uint8_t** out, uint64_t* out_size);
+
+/* ---- one stream over several devices (SURVEY 8(b) "multi-GPU fan-out lives entirely behind this shim", 8(e)) ----------
+ * The reference's LAC::Encoder::encode spreads the blocks of a stream over its worker threads and concatenates their
+ * payloads in block order (ref src/codec/lac/encoder.cpp:385-443 worker pool, :445-465 container).  An encoder created over
+ * a device list does the same with devices as the workers: lacx_encode, lacx_encode_wav and lacx_encode_wav_view cut the
+ * stream into contiguous block ranges [g*B/G, (g+1)*B/G) (lacx_fanout_range), one per lane; every lane has its own host
+ * thread, streams, workspace and pinned result region on its device, uploads its range straight from the caller's buffer
+ * and runs the single-device pipeline; the lanes exchange (payload bytes, block count) -- an RCCL all-gather of two u64
+ * per lane over xGMI when the devices are distinct, a host-side sum otherwise (RCCL refuses two ranks on one device) --
+ * and each lane copies its payload and its slice of the block table to its place in the final .lac.  The bytes do not
+ * depend on the device list (blocks are independent).  Every other entry point of such an encoder runs on its first device.
+ * devices: HIP ordinals, at most LACX_MAX_FANOUT; a device may appear more than once (a rehearsal of the fan-out on fewer
+ * GPUs than lanes).  min_blocks_per_device: a stream is spread over fewer lanes when a lane would get fewer blocks than
+ * this (0 = default 64; the reference uses min(threads, blocks) workers, encoder.cpp:385-390).
+ * lacx_config.device = LACX_DEVICE_ALL in lacx_encoder_create is the list of every visible device.  LACX_FANOUT_EXCHANGE =
+ * host | rccl (read at creation) forces the exchange. */
+#define LACX_MAX_FANOUT 16u
+int lacx_encoder_create_multi(const lacx_config* cfg, const int32_t* devices, uint32_t ndevices,
+                              uint32_t min_blocks_per_device, lacx_encoder** out);
+uint32_t lacx_encoder_lanes(const lacx_encoder* enc); /* 1 for a plain encoder */
+/* The block range of lane `lane` of `nlanes` over a stream of `nblocks` blocks. */
+void lacx_fanout_range(uint32_t nblocks, uint32_t nlanes, uint32_t lane, uint32_t* first, uint32_t* count);
+
+/* Shards already resident in device memory, shards[g] on the device of lane g (every shard but the last a whole number of
+ * blocks): every lane encodes its shard, the sizes are exchanged, out[g] views the lane's payload and block table in its
+ * pinned result region (valid until the encoder's next call) with its byte offset in the stream's payload.  No
+ * concatenation: lacx_assemble builds the .lac from the views where one contiguous buffer is wanted. */
+typedef struct lacx_fanout_shard {
+    lacx_pcm pcm; /* on the lane's device */
+    uint64_t frames;
+} lacx_fanout_shard;
+typedef struct lacx_fanout_out {
+    const uint8_t* payload;
+    uint64_t payload_size;
+    const uint32_t* table; /* (frames, bytes) per block */
+    uint32_t nblocks;
+    int32_t device;
+    uint64_t byte_offset; /* of this payload inside the concatenated payload of the stream */
+} lacx_fanout_out;
+int lacx_encode_fanout_resident(lacx_encoder* enc, const lacx_fanout_shard* shards, uint32_t nshards, lacx_fanout_out* out);
+
+#define LACX_EXCHANGE_HOST 1u
+#define LACX_EXCHANGE_RCCL 2u
+typedef struct lacx_fanout_stats {  /* of the encoder's last fanned-out call */
+    uint32_t lanes_used;
+    uint32_t exchange;               /* LACX_EXCHANGE_* */
+    double exchange_ms;              /* longest lane: its shard finished -> every lane's sizes known (includes waiting for the slowest lane) */
+    double concat_ms;                /* longest lane: table slice + payload copy into the final buffer */
+    int32_t device[LACX_MAX_FANOUT];
+    uint32_t blocks[LACX_MAX_FANOUT];
+    uint64_t lane_frames[LACX_MAX_FANOUT];
+    uint64_t payload_bytes[LACX_MAX_FANOUT];
+    double encode_ms[LACX_MAX_FANOUT]; /* the lane's shard: upload, kernels, payload in its pinned region */
+} lacx_fanout_stats;
+int lacx_get_fanout_stats(const lacx_encoder* enc, lacx_fanout_stats* out);
+int lacx_get_lane_timing(const lacx_encoder* enc, uint32_t lane, lacx_timing* out);
+const char* lacx_fanout_exchange_note(const lacx_encoder* enc); /* which exchange the encoder uses, and why */
 
 /* ---- decode: LAC::Decoder::decode, ref src/codec/lac/decoder.hpp:10-24, decoder.cpp:76-303,
  * src/codec/block/decoder.cpp:64-520.  The product's own check that a .lac gives back the PCM, on the device: one lane

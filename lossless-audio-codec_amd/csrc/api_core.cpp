@@ -5,6 +5,41 @@
 
 namespace lacx_host {
 
+Knobs read_knobs() {
+    Knobs k;
+    auto set = [](const char* name) {
+        const char* v = std::getenv(name);
+        return v != nullptr;
+    };
+    auto on = [](const char* name) {  // set, non-empty and not "0"
+        const char* v = std::getenv(name);
+        return v && *v && *v != '0';
+    };
+    auto num = [](const char* name) -> unsigned long long {
+        const char* v = std::getenv(name);
+        return v ? std::strtoull(v, nullptr, 0) : 0ull;
+    };
+    k.stream_priority = !set("LACX_NO_STREAM_PRIORITY");
+    if (const char* v = std::getenv("LACX_FUSED_EMIT")) k.fused_emit = *v != '0';
+    k.emit_staged = on("LACX_EMIT_STAGED");
+    k.direct_packer = set("LACX_DIRECT_PACKER");
+    k.packer = !set("LACX_NO_PACKER");
+    k.chain = !set("LACX_NO_CHAIN");
+    k.persistent = !set("LACX_NO_PERSISTENT");
+    k.debug_drain = set("LACX_DEBUG_DRAIN");
+    k.two_copy_streams = !set("LACX_ONE_COPY_STREAM");
+    k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
+    k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");
+    k.pipe_chunks = (uint32_t)num("LACX_PIPE_CHUNKS");
+    if (const char* v = std::getenv("LACX_PIPE_SPLIT")) k.pipe_split = v;
+    k.drain_fence = (uint32_t)num("LACX_DRAIN_FENCE");
+    if (const char* v = std::getenv("LACX_FANOUT_EXCHANGE")) k.fanout_exchange = std::strcmp(v, "host") == 0 ? 1u : (std::strcmp(v, "rccl") == 0 ? 2u : 0u);
+    k.tune.persistent_grid = (uint32_t)num("LACX_PERSISTENT_GRID");
+    k.tune.pack_nap = (int)num("LACX_PACK_NAP");
+    k.tune.pack_grid = (int)num("LACX_PACK_GRID");
+    return k;
+}
+
 double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
 int fail(lacx_encoder* e, int code, const std::string& msg) {
@@ -53,7 +88,7 @@ int ensure_device(lacx_encoder* e) {
         // analysis first and their emit (PCIe-bound) runs under the later chunks' analysis.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const bool prio = std::getenv("LACX_NO_STREAM_PRIORITY") == nullptr && greatest < least;
+        const bool prio = e->knobs.stream_priority && greatest < least;
         int i = 0;
         for (auto& s : e->stream) {
             if (prio) {
@@ -240,8 +275,7 @@ AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, 
     prm.bit_depth = bit_depth;
     prm.zero_run = e->cfg.zero_run_enabled ? 1 : 0;
     prm.partitioning = e->cfg.partitioning_enabled ? 1 : 0;
-    const char* dbg = std::getenv("LACX_DEBUG_SKIP");  // timing ablations only
-    prm.debug_skip = dbg ? (uint32_t)std::strtoul(dbg, nullptr, 0) : 0u;
+    prm.debug_skip = e->knobs.debug_skip;  // test hooks / ablations (only a -DLACX_TEST_HOOKS library looks at it)
     return prm;
 }
 
@@ -283,7 +317,7 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
 // Host emit wants many chunks (emit of chunk i overlaps the analysis of chunk i+1); with the emit on the
 // device the only host work is a copy, and two chunks (payload copy of one under the kernels of the other)
 // measured best.
-std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit, bool fused, bool upload) {
+std::vector<Chunk> plan_chunks(const Knobs& kn, uint32_t nb, bool device_emit, bool fused, bool upload) {
     uint32_t nchunks = nb / kMinChunkBlocks;
     // device emit without the fused path: 3 chunks up to an hour of stereo 48 kHz per call, 4 and 6 beyond (measured on a
     // 2 h shard).  With the fused emit + streaming packer nothing is left to overlap by chunking -- the payload leaves
@@ -295,15 +329,12 @@ std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit, bool fused, bool u
     const uint32_t dev_chunks = fused ? (upload ? 3u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
     nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
-    if (const char* env = std::getenv("LACX_PIPE_CHUNKS")) {  // tuning knob
-        const unsigned long v = std::strtoul(env, nullptr, 0);
-        if (v >= 1 && v <= (unsigned long)kMaxChunks) {
-            nchunks = std::min<uint32_t>((uint32_t)v, nb);
-            forced = true;
-        }
+    if (kn.pipe_chunks >= 1 && kn.pipe_chunks <= (uint32_t)kMaxChunks) {  // tuning knob
+        nchunks = std::min<uint32_t>(kn.pipe_chunks, nb);
+        forced = true;
     }
     std::vector<Chunk> out;
-    const char* split_env = std::getenv("LACX_PIPE_SPLIT");  // tuning knob: relative chunk sizes, e.g. "5,3,1"
+    const char* split_env = kn.pipe_split.empty() ? nullptr : kn.pipe_split.c_str();  // tuning knob: relative chunk sizes, e.g. "5,3,1"
     // Device emit: three chunks on three streams of falling priority, the last one a little smaller -- its
     // emit is the only one whose PCIe writes are not hidden under another chunk's analysis (measured best).
     if (!split_env && !forced && device_emit && nchunks == 3u) split_env = (fused && upload) ? "1,3,4" : "5,5,4";
@@ -361,6 +392,7 @@ void count_slots(lacx_encoder* e, uint32_t first, uint32_t count) {
 
 // Sample-range errors in the reference's order: all of left first, then right (ref lac/encoder.cpp:238-241).
 int check_sample_range(lacx_encoder* e, uint32_t nb) {
+    e->bad_channel = -1;
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t b = 0; b < nb; ++b) {
             const BlockPlan& bp = e->h_bplans[b];
@@ -369,6 +401,8 @@ int check_sample_range(lacx_encoder* e, uint32_t nb) {
             // per block the left channel wins the minimum, so a "right" entry means a clean left channel
             if ((pass == 0) == is_right) continue;
             const uint64_t idx = (uint64_t)b * kMaxBlock + (bp.first_bad & 0x7FFFFFFFu);
+            e->bad_channel = is_right ? 1 : 0;
+            e->bad_index = idx;
             return fail(e, LACX_E_INVALID,
                         std::string(is_right ? "right" : "left") + " sample at index " + std::to_string(idx) +
                             " is outside the configured PCM bit depth");
@@ -455,14 +489,24 @@ int lacx_device_count(void) {
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out) {
     if (!cfg || !out) return LACX_E_INVALID;
+    if (cfg->device == LACX_DEVICE_ALL) {  // every visible device (counting them does not initialise one)
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n < 1) n = 1;
+        n = std::min<int>(n, (int)LACX_MAX_FANOUT);
+        int32_t devs[LACX_MAX_FANOUT];
+        for (int i = 0; i < n; ++i) devs[i] = i;
+        return lacx_encoder_create_multi(cfg, devs, (uint32_t)n, 0, out);
+    }
     lacx_encoder* e = new lacx_encoder();
     e->cfg = *cfg;
+    e->knobs = read_knobs();
     *out = e;
     return LACX_OK;
 }
 
 void lacx_encoder_destroy(lacx_encoder* e) {
     if (!e) return;
+    destroy_fanout(e);  // the lanes' threads, communicators and child encoders first
     e->pool.reset();
     std::free(e->view_buf);
     std::free(e->view_table);
@@ -494,7 +538,9 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->h_err) (void)hipHostFree(e->h_err);
         if (e->h_emitted) (void)hipHostFree(e->h_emitted);
         if (e->h_tspan) (void)hipHostFree(e->h_tspan);
-
+        if (e->h_range) (void)hipHostFree(e->h_range);
+        if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+        if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
         for (auto& s : e->stream)
             if (s) (void)hipStreamDestroy(s);
     }

@@ -2,6 +2,62 @@
 // single blocks (Block::Encoder), container assembly, and the kernel-level probes the parity tests use.
 #include "encoder_impl.h"
 
+namespace lacx_host {
+
+// Device buffer for a WAV data chunk of `bytes` bytes (+ the look-ahead the staging loads may touch).
+static int ensure_raw(lacx_encoder* e, uint64_t bytes) {
+    if (bytes + 16u > e->d_raw_cap) {
+        if (e->d_raw) (void)hipFree(e->d_raw);
+        e->d_raw = nullptr;
+        e->d_raw_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_raw, bytes + 16u), "hipMalloc(wav data)");
+        e->d_raw_cap = bytes + 16u;
+    }
+    return LACX_OK;
+}
+
+// One lane's work in a fan-out, and what a plain encoder does with host input: the frames of hs on e's device, upload
+// pipelined with the kernels; results are views into e's buffers.
+int encode_host_shard_view(lacx_encoder* e, const HostSrc& hs, int layout, int channels, uint64_t frames, const uint8_t** payload,
+                           uint64_t* payload_size, const uint32_t** table, uint32_t* nblocks) {
+    int rc = prepare(e, hs.p0, frames);
+    if (rc) return rc;
+    const int32_t* left = reinterpret_cast<const int32_t*>(hs.p0);
+    const int32_t* right = reinterpret_cast<const int32_t*>(hs.p1);
+    if (layout == 0 && (e->cfg.flags & LACX_FLAG_HOST_EMIT)) {  // north_star layout: plans back, bit emit on host threads
+        rc = upload(e, left, right, frames);
+        if (rc) return rc;
+        return lacx_encode_shard_device_view(e, e->d_left, right ? e->d_right : nullptr, left, right, frames, nullptr, payload,
+                                             payload_size, table, nblocks);
+    }
+    const int32_t *dl, *dr = nullptr;
+    if (layout == 0) {
+        rc = ensure_pcm(e, frames, right != nullptr);
+        if (rc) return rc;
+        dl = e->d_left;
+        dr = right ? e->d_right : nullptr;
+    } else {
+        rc = ensure_raw(e, frames * hs.frame_bytes);
+        if (rc) return rc;
+        dl = reinterpret_cast<const int32_t*>(e->d_raw);
+    }
+    uint64_t pay = 0;
+    rc = encode_pipelined_device(e, dl, dr, frames, nullptr, &pay, layout, channels, &hs);
+    if (rc == -1) {
+        if (layout != 0) return fail(e, LACX_E_RUNTIME, "payload exceeds the pinned result reservation");
+        // (only with LACX_EMIT_STAGED) the host-emit pipeline; the PCM is on the device already
+        return lacx_encode_shard_device_view(e, dl, dr, left, right, frames, nullptr, payload, payload_size, table, nblocks);
+    }
+    if (rc) return rc;
+    *payload = e->h_payload;
+    *payload_size = pay;
+    *table = e->h_table;
+    *nblocks = blocks_for(frames);
+    return LACX_OK;
+}
+
+}  // namespace lacx_host
+
 extern "C" {
 
 int lacx_analyze_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
@@ -137,6 +193,13 @@ int lacx_encode(lacx_encoder* e, const int32_t* left, const int32_t* right, uint
     e->timing = lacx_timing{};
     int rc = prepare(e, left, frames);
     if (rc) return rc;
+    if (is_fanout(e)) {  // the blocks spread over the encoder's devices (api_fanout.cpp)
+        HostSrc hs;
+        hs.p0 = reinterpret_cast<const uint8_t*>(left);
+        hs.p1 = reinterpret_cast<const uint8_t*>(right);
+        hs.frame_bytes = sizeof(int32_t);
+        return fanout_encode_host(e, hs, 0, right ? 2 : 1, frames, true, out, out_size);
+    }
     if (!(e->cfg.flags & LACX_FLAG_HOST_EMIT)) {
         // device emit: the upload is pipelined with the analysis (chunk c+1's PCM crosses PCIe under chunk c's kernels)
         rc = ensure_pcm(e, frames, right != nullptr);
@@ -373,13 +436,18 @@ static int encode_wav_in_place(lacx_encoder* e, const uint8_t* wav, uint64_t siz
                                            std::to_string((int)w.bit_depth) + " bit) differs from the encoder's");
     int rc = prepare(e, wav + w.data_offset, w.frames);
     if (rc) return rc;
-    if (w.data_bytes + 16u > e->d_raw_cap) {
-        if (e->d_raw) (void)hipFree(e->d_raw);
-        e->d_raw = nullptr;
-        e->d_raw_cap = 0;
-        HIP_TRY(e, hipMalloc((void**)&e->d_raw, w.data_bytes + 16u), "hipMalloc(wav data)");
-        e->d_raw_cap = w.data_bytes + 16u;
+    if (is_fanout(e)) {
+        HostSrc fs;
+        fs.p0 = wav + w.data_offset;
+        fs.frame_bytes = (uint64_t)w.channels * (w.bit_depth / 8u);
+        uint8_t* buf = nullptr;
+        rc = fanout_encode_host(e, fs, w.bit_depth == 16 ? (int)LACX_PCM_INTERLEAVED_I16 : (int)LACX_PCM_INTERLEAVED_I24,
+                                (int)w.channels, w.frames, false, &buf, out_size);
+        *out = buf;
+        return rc;
     }
+    rc = ensure_raw(e, w.data_bytes);
+    if (rc) return rc;
     // The data chunk as it is in the file: interleaved little-endian int16 / packed int24 (coalesced ingest), uploaded
     // chunk by chunk in front of each pipeline chunk's kernels (the upload of chunk c+1 overlaps the analysis of chunk c).
     HostSrc hs;

@@ -53,7 +53,7 @@ int encode_pipelined(lacx_encoder* e, const int32_t* d_left, const int32_t* d_ri
     int rc = ensure_workspace(e, nb);
     if (rc) return rc;
     const StreamParams sp = stream_params(e->cfg, channels);
-    const std::vector<Chunk> chunks = plan_chunks(nb);
+    const std::vector<Chunk> chunks = plan_chunks(e->knobs, nb);
     const uint64_t cap = payload_upper_bound(frames, channels, nb);
     uint8_t* buf = static_cast<uint8_t*>(std::malloc(head + cap));
     if (!buf) return fail(e, LACX_E_RUNTIME, "out of memory");
@@ -186,10 +186,7 @@ ChunkCtx chunk_ctx(lacx_encoder* e, const int32_t* d_left, const int32_t* d_righ
 // exact size is only known after the analysis; a stream that needs more is re-emitted into a regrown buffer, see
 // reemit_into_regrown_buffer).  LACX_PINNED_CAP_BYTES overrides the estimate (tests force the regrow path with it).
 uint64_t pinned_reservation(const lacx_encoder* e, uint64_t frames, int channels, uint32_t nb) {
-    if (const char* env = std::getenv("LACX_PINNED_CAP_BYTES")) {
-        const unsigned long long v = std::strtoull(env, nullptr, 0);
-        if (v > 0) return (uint64_t)v;
-    }
+    if (e->knobs.pinned_cap_bytes > 0) return e->knobs.pinned_cap_bytes;
     return frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
 }
 
@@ -213,21 +210,17 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     if (rc) return rc;
     // Emit fused into the analysis kernel (default; LACX_FUSED_EMIT=0 leaves the bitstream to k_offsets + k_emit alone;
     // k_emit runs after the analysis in any case and picks up whatever the fused path did not write).
-    const char* fenv = std::getenv("LACX_FUSED_EMIT");
-    const bool fused = !(fenv && *fenv == '0');
-    e->pend.chunks = plan_chunks(nb, true, fused, hs != nullptr);
+    const Knobs& kn = e->knobs;
+    const bool fused = kn.fused_emit;
+    e->pend.chunks = plan_chunks(kn, nb, true, fused, hs != nullptr);
     const std::vector<Chunk>& chunks = e->pend.chunks;
     // Destination of k_emit: by default the pinned host buffer itself (the kernel's 16-byte stores cross PCIe
     // while later blocks are still being analysed, so no separate D2H pass is left at the end); with
     // LACX_EMIT_STAGED=1 a device arena sized for the worst case (12 bytes per sample), copied afterwards.
-    static const bool staged = [] {
-        const char* v = std::getenv("LACX_EMIT_STAGED");
-        return v && *v && *v != '0';
-    }();
+    const bool staged = kn.emit_staged;
     // Default with the fused emit: the packer packs into device memory and a copy engine drains it (LACX_DIRECT_PACKER=1:
     // the packer's CUs store straight into pinned host memory, the round-2 layout).
-    const bool drained = !staged && !(std::getenv("LACX_FUSED_EMIT") && *std::getenv("LACX_FUSED_EMIT") == '0') &&
-                         !std::getenv("LACX_DIRECT_PACKER") && !std::getenv("LACX_NO_PACKER") && !std::getenv("LACX_PINNED_CAP_BYTES");
+    const bool drained = !staged && fused && !kn.direct_packer && kn.packer && kn.pinned_cap_bytes == 0;
     if (drained) {
         const uint64_t dev_cap = pinned_reservation(e, frames, channels, nb) + 64ull;
         if (dev_cap > e->d_payload_cap) {
@@ -258,7 +251,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     }
     const uint64_t host_cap = pinned_reservation(e, frames, channels, nb);
     const uint64_t prefix = (14ull + 8ull * nb + 4095ull) & ~4095ull;  // room for the container header + block table
-    if (host_cap > e->h_payload_cap || prefix > e->h_prefix || std::getenv("LACX_PINNED_CAP_BYTES")) {
+    if (host_cap > e->h_payload_cap || prefix > e->h_prefix || kn.pinned_cap_bytes) {
         if (e->h_payload_base) (void)hipHostFree(e->h_payload_base);
         e->h_payload = e->h_payload_base = nullptr;
         e->h_payload_cap = e->h_prefix = 0;
@@ -344,7 +337,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         // Fused emit: the packer walks the stream indices in order, so the whole-block kernels of the chunks run in that
         // order too (chunk c's waits for chunk c-1's: ev[c-1][3] is recorded behind it); what comes before them --
         // ingest, Levinson, probes -- still overlaps the previous chunk's analysis.
-        const bool chain = fused && c > 0 && !std::getenv("LACX_NO_CHAIN");
+        const bool chain = fused && c > 0 && kn.chain;
         (void)cl;
         (void)cr;
         (void)prm;
@@ -352,9 +345,9 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         // persistent analysis workgroups only for a shard that is one chunk: with several, the next chunk's ingest /
         // Levinson / probe kernels are meant to run beside this chunk's analysis, which persistent workgroups would not let in
         DeviceWorkspace wl = w;
-        if (chunks.size() > 1) wl.work_ctr = nullptr;
-        HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr), "kernel launch");
-        if (c == 0 && fuse_items && !std::getenv("LACX_NO_PACKER")) {
+        if (chunks.size() > 1 || !kn.persistent) wl.work_ctr = nullptr;
+        HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr, kn.tune), "kernel launch");
+        if (c == 0 && fuse_items && kn.packer) {
             // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first
             // chunk's ingest / Levinson / probe kernels are done (ev[0][2] is recorded right in front of the whole-block
             // kernel), so its bounded waits only ever cover the progress of the analysis itself, however long the shard.
@@ -375,10 +368,10 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
                 rp.range_end = e->d_range_end;
                 HIP_TRY(e, hipHostGetDevicePointer((void**)&rp.host_end, e->h_range, 0), "hipHostGetDevicePointer");
                 rp.fuse_total = fuse_items;
-                if (const char* fm = std::getenv("LACX_DRAIN_FENCE")) rp.fence_mode = (uint32_t)std::atoi(fm);
+                rp.fence_mode = kn.drain_fence;
                 e->pend.ranges = ranges;
             }
-            HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream, rp), "packer launch");
+            HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream, rp, kn.tune), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
         }
     }
@@ -393,7 +386,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         const int32_t *cl = cx.left, *cr = cx.right;
         const DeviceWorkspace& w = cx.w;
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
-        const bool packer_counts = fuse_items && !std::getenv("LACX_NO_PACKER");
+        const bool packer_counts = fuse_items && kn.packer;
         (void)cl;
         (void)cr;
         (void)prm;
@@ -501,8 +494,8 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     // Copy-engine drain: while the kernels run, every range of stream indices the packer reports complete is fetched
     // from the device payload into the pinned result buffer (hipMemcpyAsync on its own stream: a copy engine, not CUs).
     uint64_t drained_to = 0;
-    static const bool dbg_drain = std::getenv("LACX_DEBUG_DRAIN") != nullptr;
-    static const bool two_streams = std::getenv("LACX_ONE_COPY_STREAM") == nullptr;
+    const bool dbg_drain = e->knobs.debug_drain;
+    const bool two_streams = e->knobs.two_copy_streams;
     if (e->pend.drained) {
         uint32_t next = 0;
         const volatile unsigned long long* flags = e->h_range;
@@ -572,7 +565,13 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         if (status == LACX_OK) {
             // what the ranges did not cover: the tail, and -- when the repair kernels had to place anything the packer had
             // counted as done (never seen) -- everything
-            if (e->h_err[kMaxChunks] & 4u) drained_to = 0;
+            if (e->h_err[kMaxChunks] & 4u) {
+                // (range copies of the stale bytes may still be queued on either copy stream: they must have landed before
+                // the full copy is enqueued, or one of them could overwrite what k_emit / k_pack placed later)
+                (void)hipStreamSynchronize(e->copy_stream2);
+                (void)hipStreamSynchronize(e->copy_stream);
+                drained_to = 0;
+            }
             if (off > drained_to) {
                 const hipError_t ce = hipMemcpyAsync(e->h_payload + drained_to, e->d_payload + drained_to, off - drained_to,
                                                      hipMemcpyDeviceToHost, e->copy_stream);
@@ -655,7 +654,8 @@ int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d
 // Every stream keeps its own parameters (rate, depth, channels, stereo mode, layout); the kernels resolve the stream of a
 // block from the descriptor table (StreamDesc, lacx_types.h).  One ingest / Levinson / probe / whole-block launch over
 // all blocks of all streams, one packer; every stream's payload lands in its own region of the pinned result buffer.
-int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipStream_t user_stream, lacx_batch_out* out) {
+int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipStream_t user_stream, lacx_batch_out* out,
+                 const std::vector<uint64_t>* exact_caps) {
     if (e->pend.active) return fail(e, LACX_E_RUNTIME, "an encode is already in flight on this encoder");
     std::vector<StreamDesc>& sds = e->batch_streams;
     sds.assign(n, StreamDesc{});
@@ -696,6 +696,8 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
         sd.fuse_items = (snb - (last_both_ways ? 1u : 0u)) * (uint32_t)channels;
         sd.out_base = region;
         sd.out_cap = it.frames * (uint64_t)channels * (it.bit_depth / 8u) * 5u / 4u + (uint64_t)snb * 64u + 4096u;
+        if (e->knobs.pinned_cap_bytes) sd.out_cap = e->knobs.pinned_cap_bytes;  // (tests force the second attempt with it)
+        if (exact_caps) sd.out_cap = (*exact_caps)[i];
         region += (sd.out_cap + 4095u) & ~4095ull;
         if ((uint64_t)nb + snb > 0x7FFFFFFFull / kSlotsPerBlock) return fail(e, LACX_E_INVALID, "too many blocks in one batch");
         nb += snb;
@@ -721,6 +723,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
         e->h_payload = e->h_payload_base;
         e->h_payload_cap = region;
     }
+    e->h_payload = e->h_payload_base + e->h_prefix;  // (the regions start where the shard path's payload does)
     if (nb > e->h_table_blocks) {
         if (e->h_table) (void)hipHostFree(e->h_table);
         e->h_table = nullptr;
@@ -738,10 +741,6 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     const size_t tab_bytes = ((size_t)n * sizeof(StreamDesc) + 15) & ~(size_t)15, map_bytes = (size_t)nitems * sizeof(uint16_t);
     if (tab_bytes + map_bytes > e->d_batch_cap) {
         if (e->d_batch) (void)hipFree(e->d_batch);
-        if (e->d_wide) (void)hipFree(e->d_wide);
-        if (e->h_range) (void)hipHostFree(e->h_range);
-        if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-        if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
         e->d_batch = nullptr;
         e->d_batch_cap = 0;
         HIP_TRY(e, hipMalloc((void**)&e->d_batch, tab_bytes + map_bytes), "hipMalloc(batch table)");
@@ -774,7 +773,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     DeviceWorkspace w = e->ws;
     w.t_first = e->d_tspan;
     w.t_last = e->d_tspan + kMaxChunks;
-    w.work_ctr = e->d_work_ctr;
+    w.work_ctr = e->knobs.persistent ? e->d_work_ctr : nullptr;
     FuseArgs fa;
     fa.slots = e->ws.slots;
     fa.slot_stride = e->ws.slot_stride;
@@ -783,11 +782,11 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     fa.size_rec = e->ws.size_rec;
     fa.ready_rec = e->ws.ready_rec;
     auto run = [&]() -> int {
-        HIP_TRY(e, launch_analysis(ls, w, s, e->ev[0], &fa, nullptr), "kernel launch");
-        const bool packer = !std::getenv("LACX_NO_PACKER");
+        HIP_TRY(e, launch_analysis(ls, w, s, e->ev[0], &fa, nullptr, e->knobs.tune), "kernel launch");
+        const bool packer = e->knobs.packer;
         if (packer) {
             HIP_TRY(e, hipStreamWaitEvent(e->pack_stream, e->ev[0][analysis_is_persistent(w) ? 0 : 2], 0), "stream wait");
-            HIP_TRY(e, launch_stream_out(ls, e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream), "packer launch");
+            HIP_TRY(e, launch_stream_out(ls, e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream, RangeProgress{}, e->knobs.tune), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
         }
         HIP_TRY(e, launch_emit(ls, w, emit_dst, nullptr, nullptr, nullptr, s, true, packer ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
@@ -835,8 +834,21 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
         }
     }
     if (e->h_err[0] & 1u) return fail(e, LACX_E_RUNTIME, "device emit disagrees with the analysis plan (internal error)");
-    if ((e->h_err[0] & 2u) || (e->h_err[kMaxChunks] & 2u))
-        return fail(e, LACX_E_RUNTIME, "a stream's payload exceeds its pinned result reservation");
+    if ((e->h_err[0] & 2u) || (e->h_err[kMaxChunks] & 2u)) {
+        // A stream needs more than its estimated reservation (the single-shard path re-emits into a regrown buffer, the
+        // reference never fails on size): k_offsets has run, so the block table holds every stream's exact size -- run the
+        // job once more with exact regions.
+        if (exact_caps) return fail(e, LACX_E_RUNTIME, "a stream's payload exceeds its exact result reservation (internal error)");
+        std::vector<uint64_t> caps(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t bytes = 0;
+            for (uint32_t b = 0; b < sds[i].prm.num_blocks; ++b) bytes += e->h_table[2 * ((size_t)sds[i].first_block + b) + 1];
+            caps[i] = bytes + 4096u;
+        }
+        const int rr = encode_batch(e, items, n, user_stream, out, &caps);
+        e->timing.regrows += 1;
+        return rr;
+    }
     add_chunk_timing(e, 0);
     {
         float f = 0;

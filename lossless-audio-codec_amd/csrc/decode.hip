@@ -510,11 +510,13 @@ hipError_t launch_decode(uint32_t num_blocks, int channels, int stereo_mode, int
                          const unsigned long long* byte_off, const unsigned long long* frame_off, int32_t* left,
                          int32_t* right, uint32_t* status, uint8_t* ms_flag, hipStream_t stream) {
     if (num_blocks == 0) return hipSuccess;
-    uint32_t lanes = 64;  // blocks per wave (see k_decode)
-    if (const char* v = std::getenv("LACX_DECODE_LANES")) {  // tuning knob: 1, 2, 4, ... 64
-        const int x = std::atoi(v);
-        if (x >= 1 && x <= 64 && (x & (x - 1)) == 0) lanes = (uint32_t)x;
-    }
+    static const uint32_t lanes = [] {  // blocks per wave (see k_decode); LACX_DECODE_LANES: tuning knob, read once
+        if (const char* v = std::getenv("LACX_DECODE_LANES")) {  // 1, 2, 4, ... 64
+            const int x = std::atoi(v);
+            if (x >= 1 && x <= 64 && (x & (x - 1)) == 0) return (uint32_t)x;
+        }
+        return 64u;
+    }();
     const size_t smem = kDecBytesPerCol * lanes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(kDecBytesPerCol * 64));

@@ -46,8 +46,34 @@ struct HostSrc {
 }  // namespace lacx_host
 using namespace lacx_host;
 
+// Every environment knob of the encode path, read ONCE when the encoder is created (lacx_encoder_create): no entry
+// point reads the environment afterwards.  All are tuning / diagnostic switches; none changes the bytes produced.
+struct Knobs {
+    bool stream_priority = true;   // LACX_NO_STREAM_PRIORITY unset
+    bool fused_emit = true;        // LACX_FUSED_EMIT != 0
+    bool emit_staged = false;      // LACX_EMIT_STAGED
+    bool direct_packer = false;    // LACX_DIRECT_PACKER: the packer stores into pinned host memory itself (round-2 layout)
+    bool packer = true;            // LACX_NO_PACKER unset
+    bool chain = true;             // LACX_NO_CHAIN unset
+    bool persistent = true;        // LACX_NO_PERSISTENT unset: whole-block analysis as persistent workgroups
+    bool debug_drain = false;      // LACX_DEBUG_DRAIN
+    bool two_copy_streams = true;  // LACX_ONE_COPY_STREAM unset
+    uint64_t pinned_cap_bytes = 0; // LACX_PINNED_CAP_BYTES (tests force the regrow path with it)
+    uint32_t debug_skip = 0;       // LACX_DEBUG_SKIP: test hooks (bits 10, 11, 13) / ablations; only honoured by a library
+                                   // built with -DLACX_TEST_HOOKS (liblacx_hooks.so)
+    uint32_t pipe_chunks = 0;      // LACX_PIPE_CHUNKS
+    std::string pipe_split;        // LACX_PIPE_SPLIT
+    uint32_t drain_fence = 0;      // LACX_DRAIN_FENCE
+    uint32_t fanout_exchange = 0;  // LACX_FANOUT_EXCHANGE: 0 auto (RCCL where the devices are distinct), 1 host, 2 rccl
+    LaunchTuning tune;             // LACX_PERSISTENT_GRID, LACX_PACK_NAP, LACX_PACK_GRID
+};
+
+struct Fanout;  // api_fanout.cpp: the lanes of an encoder that spreads a stream over several devices
+
 struct lacx_encoder {
     lacx_config cfg{};
+    Knobs knobs{};
+    Fanout* fan = nullptr;  // non-null: lacx_encode / lacx_encode_wav* split the stream into block ranges over fan's lanes
     bool device_ready = false;
     int device = 0;
     hipStream_t stream[kStreams] = {};
@@ -122,6 +148,8 @@ struct lacx_encoder {
     unsigned long long* d_range_end = nullptr;
     std::unique_ptr<EmitPool> pool;
     std::string err;
+    int bad_channel = -1;    // last sample-range error: 0 left / 1 right, and the sample's index in the call's input
+    uint64_t bad_index = 0;  // (the fan-out rebuilds the reference's message with the stream-wide index)
     lacx_timing timing{};
 };
 
@@ -150,7 +178,8 @@ AnalyzeParams make_params(const lacx_encoder* e, uint64_t frames, int channels, 
 LaunchSet one_stream_set(const AnalyzeParams& prm, const int32_t* left, const int32_t* right, uint32_t fuse_items = 0, uint64_t out_cap = 0);
 const LaunchSet& bind(LaunchSet& ls);
 DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block);
-std::vector<Chunk> plan_chunks(uint32_t nb, bool device_emit = false, bool fused = false, bool upload = false);
+std::vector<Chunk> plan_chunks(const Knobs& kn, uint32_t nb, bool device_emit = false, bool fused = false, bool upload = false);
+Knobs read_knobs();
 void add_chunk_timing(lacx_encoder* e, int c);
 void count_slots(lacx_encoder* e, uint32_t first, uint32_t count);
 int enqueue_chunk(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, int channels, int stereo_mode, int bit_depth, const Chunk& ck, int c, hipStream_t st);
@@ -170,6 +199,16 @@ int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_
 int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, const int32_t*& h_left, const int32_t*& h_right, std::vector<int32_t>& tl, std::vector<int32_t>& tr);
 int upload(lacx_encoder* e, const int32_t* left, const int32_t* right, uint64_t frames);
 int prepare(lacx_encoder* e, const void* left, uint64_t frames);
-int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipStream_t user_stream, lacx_batch_out* out);
+int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipStream_t user_stream, lacx_batch_out* out,
+                 const std::vector<uint64_t>* exact_caps = nullptr);
 int fill_table(lacx_encoder* e, uint8_t* buf, uint32_t nb, const std::vector<uint64_t>& offsets);
+// api_encode.cpp: `frames` frames of host PCM (layout 0: planar int32 in hs.p0 / hs.p1; 1 / 2: the WAV data chunk) on e's
+// device; the results are views into e's buffers (valid until its next call)
+int encode_host_shard_view(lacx_encoder* e, const HostSrc& hs, int layout, int channels, uint64_t frames, const uint8_t** payload,
+                           uint64_t* payload_size, const uint32_t** table, uint32_t* nblocks);
+// api_fanout.cpp
+bool is_fanout(const lacx_encoder* e);
+void destroy_fanout(lacx_encoder* e);
+int fanout_encode_host(lacx_encoder* e, const HostSrc& hs, int layout, int channels, uint64_t frames, bool owned, uint8_t** out,
+                       uint64_t* out_size);
 }  // namespace lacx_host

@@ -20,6 +20,15 @@ namespace lacx {
 __device__ unsigned long long g_stamp_acc[40];
 #endif
 
+// Test hooks and timing ablations (AnalyzeParams::debug_skip, from LACX_DEBUG_SKIP) exist only in the diagnostic library
+// (liblacx_hooks.so, -DLACX_TEST_HOOKS): bits 10 / 11 / 13 force the repair paths of the fused emit for the parity tests,
+// the other bits switch phases off for timing experiments.  The production kernel carries none of them.
+#ifdef LACX_TEST_HOOKS
+#define LACX_HOOK(prm, bits) (((prm).debug_skip & (bits)) != 0u)
+#else
+#define LACX_HOOK(prm, bits) false
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Fused emit + streaming packer.
 // The whole-block analysis kernel emits a channel block's bitstream right after its plan is final, while the winner's
@@ -63,7 +72,7 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     // a bitstream longer than the slot (never seen: it would take > 3 resp. 5 bytes per sample) is left to k_emit;
     // test hook (LACX_DEBUG_SKIP bit 10): so is every fifth channel block
     const bool skip = (unsigned long long)sh.plan.payload_bytes + 16u > fa.slot_stride ||
-                      ((prm.debug_skip & 1024u) && (idx % 5 == 3));
+                      (LACX_HOOK(prm, 1024u) && (idx % 5 == 3));
     bool done = false;
     if (!skip) {  // uniform
         emit_load_plan(sh, sh.plan, tid, G::T);
@@ -79,7 +88,7 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
         uint8_t* slot = fa.slots + (unsigned long long)idx * fa.slot_stride;
         STAMP(24);
         done = emit_body<G>(sh, th, n, slot, fa.err_flag, [slot](uint8_t** o) { *o = slot; return true; }, tid,
-                            (prm.debug_skip & 2048u) != 0u, (uint32_t)fa.slot_stride STAMP_ARGS);
+                            LACX_HOOK(prm, 2048u), (uint32_t)fa.slot_stride STAMP_ARGS);
     }
     // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
     // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1).  A persistent
@@ -88,7 +97,7 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     if (defer) {
         defer->idx = idx;
         defer->done = done;
-        defer->silent = (prm.debug_skip & 8192u) != 0u;
+        defer->silent = LACX_HOOK(prm, 8192u);
         return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -96,7 +105,7 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     if (tid == 0) {
         if (done) fa.emitted[idx] = 2u;  // for the kernels that run after this one (k_pack)
         // test hook (bit 13): the slot is filled but never announced, so the packer gives up and k_pack takes over
-        if (!(prm.debug_skip & 8192u)) rec_store(&fa.ready_rec[idx], done ? 1ull : 2ull);
+        if (!LACX_HOOK(prm, 8192u)) rec_store(&fa.ready_rec[idx], done ? 1ull : 2ull);
     }
 }
 
@@ -216,7 +225,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
         // addresses and masks derived from it and, at the 128-VGPR budget, spills them to scratch.
         asm volatile("" : "+v"(th.a));
-        const bool lpc_off = (prm.debug_skip & 16u) != 0u;
+        const bool lpc_off = LACX_HOOK(prm, 16u);
         // bit_width(u | 1) + 1 = 33 - clz(u | 1) = 34 - lead_m per position.  A zero counts 2 that way and is worth 1 (the
         // wave's zero count takes the difference out); a position beyond the slot (r = 0) counts 2, is among those zeros
         // and is worth nothing (the wave's `beyond` takes the rest out).
@@ -267,8 +276,8 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     __syncthreads();
     if (tid <= 10) {
         // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
-        const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || (prm.debug_skip & 16u))) ||
-                             (tid >= 1 && (prm.debug_skip & 64u)));
+        const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || LACX_HOOK(prm, 16u))) ||
+                             (tid >= 1 && LACX_HOOK(prm, 64u)));
         sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], sh.lbacc[tid][2], n, prm.zero_run) << 4) | (uint64_t)tid)
                                  : ~0ull;
     }
@@ -299,7 +308,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                 sh.has4[parity] = 0;
                 sh.bqcount = 0;
                 int next = best_key == ~0ull ? -1 : (int)(best_key & 15u);
-                if (next >= 0 && !(prm.debug_skip & 128u) && candidate_pruned(best_key >> 4, next, sh.best_bits, sh.best_cand)) next = -1;
+                if (next >= 0 && !LACX_HOOK(prm, 128u) && candidate_pruned(best_key >> 4, next, sh.best_bits, sh.best_cand)) next = -1;
                 sh.next_cand = next;
             }
         }
@@ -324,8 +333,8 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         __syncthreads();  // B1b: the wave totals of the scan
         const uint64_t total_u = scan_pz_part2(sh, tid, sr);
         const bool narrow = total_u < kNarrowLimit;  // all prefix sums fit 32 bits (uniform)
-        const bool ksums = narrow && !(prm.debug_skip & 262144u);
-        if (!(prm.debug_skip & 1u)) {
+        const bool ksums = narrow && !LACX_HOOK(prm, 262144u);
+        if (!LACX_HOOK(prm, 1u)) {
             if (ksums) ksums_wave(th, pt, pt256, tid); else plane_totals_wave(th, pt, pt256, tid);
         }
         // the first 256 samples all belong to wave 0: its own totals are complete once its atomics are (same wave,
@@ -335,7 +344,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             if (tid == 0) sh.cur_k0 = k0w;
         }
         STAMP(6);
-        if (prm.debug_skip & 2u) {
+        if (LACX_HOOK(prm, 2u)) {
             sh.tabF[tid] = 0;
             th.has4 = 1u;
         } else if (narrow) {
@@ -351,14 +360,14 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         // (nothing derived from the thread index is carried from outside the candidate loop into phase B: the compiler
         // would keep a dozen LDS addresses alive across pass 1 and the loop, in scratch memory)
         asm volatile("" : "+v"(th.tid));
-        if (prm.debug_skip & 4u) {
+        if (LACX_HOOK(prm, 4u)) {
             th.crice = th.cbin = th.czr = 1;
             th.chasrun = 0;
         } else {
             // the zero-run cost only matters when the residual has a run of >= 4 zeros somewhere
             const bool zr = prm.zero_run && sh.has4[parity] != 0u;
             const bool full = n == (uint32_t)G::MAXN;
-            if (G::T == 64 || (prm.debug_skip & 524288u)) {
+            if (G::T == 64 || LACX_HOOK(prm, 524288u)) {
                 phase_b_dispatch<G>(th, sh, k0, narrow, zr, full);
                 if ((uint32_t)th.a >= n) {
                     th.crice = th.cbin = th.czr = 0;
@@ -436,7 +445,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         }
         if (tid <= G::MAXP) pm.pbits[tid] = 0;
     };
-    if (best == pending && !(prm.debug_skip & 16384u)) {
+    if (best == pending && !LACX_HOOK(prm, 16384u)) {
         // The winner is the candidate evaluated last (usually the only one): its residual is still in sh.u, with the
         // micro-window flags of phase A in bits 30/31, its prefix sums in tabP / tabNZ, its plane counts in th.cs.
         // Strip the flags; nobody reads the staged samples any more (the last barrier of the search is behind us).
@@ -479,7 +488,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         }
         __syncthreads();
         STAMP(17);
-        for (int idx = tid; idx < ((prm.debug_skip & 32u) ? 0 : nseg); idx += G::T) {
+        for (int idx = tid; idx < (LACX_HOOK(prm, 32u) ? 0 : nseg); idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
         }
@@ -492,7 +501,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             atomicAdd(&pm.segacc[idx][2], zr);
             if (hr) atomicOr(&pm.segrun[idx], 1u);
         };
-        if (prm.debug_skip & 8u) {
+        if (LACX_HOOK(prm, 8u)) {
             // (timing ablation only)
         } else if (pnarrow && partitions_chunk_aligned<G>(n, max_p)) {
             // all orders in one walk (every full block, every probe); without a run of >= 4 zeros in the
@@ -502,9 +511,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             // One atomic per accumulator and segment of neighbouring lanes (see seg_sum_u32): the lanes of a partition of
             // order p are (n >> p) / CH neighbours -- a power of two for every full block and every probe; other sizes
             // fall back to one atomic per lane.  Called by every lane of the wave (idle lanes pass zeros).
-            const bool ablate_flush = (prm.debug_skip & 65536u) != 0u;
+            const bool ablate_flush = LACX_HOOK(prm, 65536u);
             const uint32_t chunks = n / (uint32_t)G::CH;  // chunks of the slot
-            const bool pow2 = (chunks & (chunks - 1u)) == 0u && !(prm.debug_skip & 131072u);
+            const bool pow2 = (chunks & (chunks - 1u)) == 0u && !LACX_HOOK(prm, 131072u);
             auto seg_flush = [&](int q, uint32_t idx, uint32_t rc, uint32_t bn, uint32_t zr, uint32_t hr, bool with_zr) {
                 if (ablate_flush) return;
                 const uint32_t lanes = chunks >> (q + 1);  // lanes per partition of this order (wave-uniform)
@@ -541,7 +550,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                 if (hr) atomicOr(&pm.segrun[idx], 1u);
             };
             const bool with_zr = prm.zero_run && sh.best_hasrun;  // (block-uniform)
-            if (prm.debug_skip & 32768u) {  // (A/B: the plain walk over every sample and order)
+            if (LACX_HOOK(prm, 32768u)) {  // (A/B: the plain walk over every sample and order)
                 if (with_zr) partition_fused<G, true>(th, sh, max_p, flush32);
                 else partition_fused<G, false>(th, sh, max_p, flush32_nozr);
             } else {
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
                 sd = stream_of_workgroup(br, v);
                 const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
                 uint32_t lblk;
-                xcd_slot(v - sd.first_wg, per, (sd.prm.debug_skip & 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
+                xcd_slot(v - sd.first_wg, per, LACX_HOOK(sd.prm, 512u) ? 0u : sd.prm.num_blocks, lblk, wsel);
                 blk = sd.first_block + lblk;
             }
             int which = (int)wsel + which_base;
@@ -800,7 +809,7 @@ static uint32_t compute_units() {
 }
 
 hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
-                           const FuseArgs* fuse, hipEvent_t wait_before_full) {
+                           const FuseArgs* fuse, hipEvent_t wait_before_full, const LaunchTuning& tune) {
     const FuseArgs fa = fuse ? *fuse : FuseArgs{};
     hipError_t e = ensure_kernel_attrs();
     if (e != hipSuccess) return e;
@@ -843,8 +852,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     // is resident by then (it is started in front of the ingest kernel in this form); the two or three workgroups that
     // find its CUs taken wait, start when the others have left, find no work and leave.
     const bool persistent = analysis_is_persistent(ws);
-    uint32_t pgrid = compute_units();
-    if (const char* v = std::getenv("LACX_PERSISTENT_GRID")) pgrid = std::atoi(v) > 0 ? (uint32_t)std::atoi(v) : pgrid;  // tuning knob
+    const uint32_t pgrid = tune.persistent_grid ? tune.persistent_grid : compute_units();
     const uint32_t grid = persistent ? (total_wg < pgrid ? total_wg : pgrid) : total_wg;
     hipLaunchKernelGGL(k_analyze<GFull>, dim3(grid), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
                        ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa, persistent ? ws.work_ctr : (uint32_t*)nullptr,

@@ -479,11 +479,10 @@ hipError_t launch_gather(const GatherList& g, hipStream_t stream) {
 
 static_assert(kRangeItems == kPackerRangeItems, "host and device agree on the range size");
 hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
-                             hipStream_t stream, const RangeProgress& rp) {
+                             hipStream_t stream, const RangeProgress& rp, const LaunchTuning& tune) {
     if (ls.total_items == 0) return hipSuccess;
-    int nap = 1, grid = rp.host_end ? kStreamGridDevice : kStreamGrid;  // tuning knobs
-    if (const char* v = std::getenv("LACX_PACK_NAP")) nap = std::atoi(v) > 0 ? std::atoi(v) : 1;
-    if (const char* v = std::getenv("LACX_PACK_GRID")) grid = std::atoi(v) > 0 ? std::atoi(v) : grid;
+    const int nap = tune.pack_nap > 0 ? tune.pack_nap : 1;
+    const int grid = tune.pack_grid > 0 ? tune.pack_grid : (rp.host_end ? kStreamGridDevice : kStreamGrid);
     // counters: [0] error flags, [1] channel blocks put in place, [2] packer waves that gave up waiting
     hipLaunchKernelGGL(k_stream_out, dim3((uint32_t)grid), dim3(kStreamThreads), 0, stream, ls.br, ls.total_items, nap, ls.item_stream,
                        (const unsigned long long*)ws.size_rec, (const unsigned long long*)ws.ready_rec, (const uint8_t*)ws.slots,

@@ -43,9 +43,14 @@ struct DeviceWorkspace {
 // the zeroed counters.  The streaming packer must then be resident BEFORE that kernel starts: persistent workgroups never
 // retire, and a packer that arrives after them finds no CU until the analysis is over (its workgroups are dealt to XCDs
 // and shader engines round-robin, whether or not a CU is free there).
-inline bool analysis_is_persistent(const DeviceWorkspace& ws) {
-    return ws.work_ctr != nullptr && std::getenv("LACX_NO_PERSISTENT") == nullptr;
-}
+inline bool analysis_is_persistent(const DeviceWorkspace& ws) { return ws.work_ctr != nullptr; }
+
+// Launch-shape tuning (read from the environment once, when the encoder is created: Knobs in encoder_impl.h).
+struct LaunchTuning {
+    uint32_t persistent_grid = 0;  // workgroups of the persistent whole-block analysis (0 = one per CU)
+    int pack_nap = 0;              // the streaming packer's polling pause (0 = default)
+    int pack_grid = 0;             // the streaming packer's workgroups (0 = default)
+};
 
 // Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while
 // the analysis runs (one stream).  host_end == nullptr: off.
@@ -111,7 +116,8 @@ hipError_t launch_gather(const GatherList& g, hipStream_t stream);
 // ev: optional 5 events recorded at: start, after ingest+levinson, after probes+decide, after the
 // whole-block analysis kernel, end.  wait_before_full: optional event the whole-block analysis kernel waits for.
 hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipStream_t stream, hipEvent_t* ev,
-                           const FuseArgs* fuse = nullptr, hipEvent_t wait_before_full = nullptr);
+                           const FuseArgs* fuse = nullptr, hipEvent_t wait_before_full = nullptr,
+                           const LaunchTuning& tune = LaunchTuning{});
 
 // Device-side emit of the analysed blocks of one set into the result buffer `out` (every stream at its
 // StreamDesc::out_base): k_offsets (block byte offsets), k_pack (channel blocks the fused emit left in their staging
@@ -131,7 +137,8 @@ hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* 
 // slots of the set's stream indices to their place in `out` as they are published.  counters: [0] error flags, [1] the
 // number of channel blocks it has put in place, [2] packer waves that gave up waiting for a record.
 hipError_t launch_stream_out(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out, uint32_t* counters,
-                             hipStream_t stream, const RangeProgress& rp = RangeProgress{});
+                             hipStream_t stream, const RangeProgress& rp = RangeProgress{},
+                             const LaunchTuning& tune = LaunchTuning{});
 
 // The decoder (decode.hip): one lane per block; payload must be followed by kDecodeTailPad readable zero bytes (the bit
 // reader's bounded look-ahead past the last block, see BitIn).

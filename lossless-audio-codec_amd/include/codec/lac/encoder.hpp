@@ -29,7 +29,8 @@ public:
         : order(o.order), stereo_mode(o.stereo_mode), sample_rate(o.sample_rate), bit_depth(o.bit_depth),
           debug_lpc(o.debug_lpc), debug_stereo_est(o.debug_stereo_est), debug_zr(o.debug_zr),
           zero_run_enabled(o.zero_run_enabled), partitioning_enabled(o.partitioning_enabled),
-          debug_partitions(o.debug_partitions), thread_count(o.thread_count), enc(nullptr) {}
+          debug_partitions(o.debug_partitions), thread_count(o.thread_count), devices(o.devices),
+          min_blocks_per_device(o.min_blocks_per_device), enc(nullptr) {}
     Encoder& operator=(const Encoder& o) {
         if (this != &o) {
             reset();
@@ -44,6 +45,8 @@ public:
             partitioning_enabled = o.partitioning_enabled;
             debug_partitions = o.debug_partitions;
             thread_count = o.thread_count;
+            devices = o.devices;
+            min_blocks_per_device = o.min_blocks_per_device;
         }
         return *this;
     }
@@ -80,6 +83,14 @@ public:
         if (thread_count != max_threads) reset();
         thread_count = max_threads;
     }
+    // Not in the reference: the devices encode() spreads the stream's blocks over, the way the reference spreads them over
+    // its worker threads (src/codec/lac/encoder.cpp:385-443).  Default (empty list): every visible device; a stream is
+    // spread over fewer when a device would get fewer than min_blocks blocks (0 = the library's default, 64).
+    void set_devices(const std::vector<int>& list, uint32_t min_blocks = 0) {
+        reset();
+        devices.assign(list.begin(), list.end());
+        min_blocks_per_device = min_blocks;
+    }
 
 private:
     lacx_encoder* handle() {
@@ -90,9 +101,12 @@ private:
             cfg.stereo_mode = stereo_mode;
             cfg.zero_run_enabled = zero_run_enabled;
             cfg.partitioning_enabled = partitioning_enabled;
-            cfg.device = -1;
+            cfg.device = LACX_DEVICE_ALL;
             cfg.emit_threads = static_cast<uint32_t>(thread_count);
-            if (lacx_encoder_create(&cfg, &enc) != LACX_OK) throw std::runtime_error("lacx_encoder_create failed");
+            const int rc = devices.empty() ? lacx_encoder_create(&cfg, &enc)
+                                           : lacx_encoder_create_multi(&cfg, devices.data(), static_cast<uint32_t>(devices.size()),
+                                                                       min_blocks_per_device, &enc);
+            if (rc != LACX_OK) throw std::runtime_error("lacx_encoder_create failed");
         }
         return enc;
     }
@@ -112,6 +126,8 @@ private:
     bool partitioning_enabled = true;
     bool debug_partitions = false;
     size_t thread_count = 0;
+    std::vector<int32_t> devices;
+    uint32_t min_blocks_per_device = 0;
     lacx_encoder* enc = nullptr;
 };
 

@@ -18,6 +18,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblacx.so")
+# the diagnostic twin (analysis kernel built with -DLACX_TEST_HOOKS: honours LACX_DEBUG_SKIP); tests and timing
+# experiments select it explicitly with use_library(HOOKS_LIB_PATH) -- the product never loads it by itself
+HOOKS_LIB_PATH = os.path.join(HERE, "liblacx_hooks.so")
+DEVICE_ALL = -2
+MAX_FANOUT = 16
 
 OK, E_INVALID, E_RUNTIME, E_DEVICE = 0, 1, 2, 3
 MAX_BLOCK = 16384
@@ -92,6 +97,8 @@ EXPORTS = (
     "lacx_block_plan_only", "lacx_debug_lpc", "lacx_debug_stamps", "lacx_device_count", "lacx_wav_parse",
     "lacx_encode_wav", "lacx_encode_shard_pcm_device_begin", "lacx_encode_shard_end", "lacx_debug_emit_workers", "lacx_encode_wav_view",
     "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error", "lacx_encode_batch_device",
+    "lacx_encoder_create_multi", "lacx_encoder_lanes", "lacx_fanout_range", "lacx_encode_fanout_resident",
+    "lacx_get_fanout_stats", "lacx_get_lane_timing", "lacx_fanout_exchange_note",
 )
 
 
@@ -99,18 +106,31 @@ def build(force: bool = False) -> str:
     """Compiles liblacx.so in-tree (hipcc cross-compiles gfx950 without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["make", "-C", HERE, "liblacx.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "liblacx.so", "liblacx_hooks.so"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
 _lib = None
+_lib_path = LIB_PATH
+_libs = {}
+
+
+def use_library(path: str | None = None):
+    """Selects the shared library the binding calls from now on (None: the product's liblacx.so).  For the parity tests
+    that need the hooks build and for A/B experiments of differently built libraries (scripts/kexp.py); encoders created
+    before the switch must not be used after it."""
+    global _lib, _lib_path
+    _lib_path = path or LIB_PATH
+    _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        # diagnostic: A/B runs of differently built libraries (scripts/kexp.py); never set in production
-        path = os.environ.get("LACX_LIB_OVERRIDE") or LIB_PATH
+        path = _lib_path
+        if path in _libs:
+            _lib = _libs[path]
+            return _lib
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: build it with `make -C {HERE}` (or __graft_entry__.build()); "
@@ -123,6 +143,12 @@ def lib():
         L.lacx_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.lacx_device_count.restype = C.c_int
         L.lacx_decode_last_error.restype = C.c_char_p
+        L.lacx_fanout_exchange_note.restype = C.c_char_p
+        L.lacx_fanout_exchange_note.argtypes = [C.c_void_p]
+        L.lacx_encoder_lanes.restype = C.c_uint32
+        L.lacx_encoder_lanes.argtypes = [C.c_void_p]
+        L.lacx_fanout_range.restype = None
+        _libs[path] = L
         _lib = L
     return _lib
 
@@ -154,10 +180,14 @@ class Encoder:
 
     def __init__(self, order: int = 12, stereo_mode: int = 0, sample_rate: int = 44100, bit_depth: int = 16,
                  debug_lpc: bool = False, debug_stereo_est: bool = False, debug_zr: bool = False,
-                 device: int = -1):
+                 device: int = -1, devices=None, min_blocks_per_device: int = 0):
+        """device: HIP ordinal, -1 = the current device, DEVICE_ALL = every visible device.  devices: an explicit device list
+        (lacx_encoder_create_multi): encode / encode_wav / encode_wav_view spread the stream's blocks over them."""
         self.order = order  # stored and ignored, as in the reference (ref block/encoder.cpp:41)
         self._cfg = Config(sample_rate & 0xFFFFFFFF, bit_depth & 0xFF, stereo_mode & 0xFF, 1, 1, device, 0, 0)
         self._raw_stereo_mode = stereo_mode
+        self._devices = None if devices is None else [int(d) for d in devices]
+        self._min_blocks = int(min_blocks_per_device)
         self._h = None
 
     # -- setters of the reference ------------------------------------------------------------
@@ -190,11 +220,50 @@ class Encoder:
     def _handle(self):
         if self._h is None:
             h = C.c_void_p()
-            rc = lib().lacx_encoder_create(C.byref(self._cfg), C.byref(h))
+            if self._devices is not None:
+                devs = (C.c_int32 * len(self._devices))(*self._devices)
+                rc = lib().lacx_encoder_create_multi(C.byref(self._cfg), devs, C.c_uint32(len(self._devices)),
+                                                     C.c_uint32(self._min_blocks), C.byref(h))
+            else:
+                rc = lib().lacx_encoder_create(C.byref(self._cfg), C.byref(h))
             if rc != OK:
                 raise RuntimeError("lacx_encoder_create failed")
             self._h = h
         return self._h
+
+    # -- the fan-out over several devices ------------------------------------------------------------
+    def lanes(self) -> int:
+        return int(lib().lacx_encoder_lanes(self._handle()))
+
+    def fanout_stats(self) -> "FanoutStats":
+        st = FanoutStats()
+        lib().lacx_get_fanout_stats(self._handle(), C.byref(st))
+        return st
+
+    def fanout_exchange_note(self) -> str:
+        return lib().lacx_fanout_exchange_note(self._handle()).decode(errors="replace")
+
+    def lane_timing(self, lane: int) -> Timing:
+        t = Timing()
+        if lib().lacx_get_lane_timing(self._handle(), C.c_uint32(lane), C.byref(t)) != OK:
+            raise ValueError("no such lane")
+        return t
+
+    def encode_fanout_resident(self, shards):
+        """shards: [(data_ptr, layout, channels, frames[, data1_ptr]), ...], shard g resident on the device of lane g.
+        Returns [(PayloadView, table, device, byte_offset), ...] (views into the lanes' pinned result regions)."""
+        n = len(shards)
+        ins = (FanoutShard * n)()
+        for it, sh in zip(ins, shards):
+            it.pcm = Pcm(sh[0], sh[4] if len(sh) > 4 else None, sh[1], sh[2])
+            it.frames = sh[3]
+        outs = (FanoutOut * n)()
+        h = self._handle()
+        rc = lib().lacx_encode_fanout_resident(h, ins, C.c_uint32(n), outs)
+        if rc != OK:
+            _raise(h, rc)
+        return [(PayloadView(o.payload, o.payload_size), np.ctypeslib.as_array(o.table, shape=(o.nblocks, 2)), int(o.device),
+                 int(o.byte_offset)) for o in outs]
 
     def close(self):
         self._reset()
@@ -413,6 +482,31 @@ class Encoder:
 
 class Pcm(C.Structure):
     _fields_ = [("data0", C.c_void_p), ("data1", C.c_void_p), ("layout", C.c_uint32), ("channels", C.c_uint32)]
+
+
+class FanoutShard(C.Structure):
+    _fields_ = [("pcm", Pcm), ("frames", C.c_uint64)]
+
+
+class FanoutOut(C.Structure):
+    _fields_ = [("payload", C.POINTER(C.c_uint8)), ("payload_size", C.c_uint64), ("table", C.POINTER(C.c_uint32)),
+                ("nblocks", C.c_uint32), ("device", C.c_int32), ("byte_offset", C.c_uint64)]
+
+
+EXCHANGE_HOST, EXCHANGE_RCCL = 1, 2
+
+
+class FanoutStats(C.Structure):
+    _fields_ = [("lanes_used", C.c_uint32), ("exchange", C.c_uint32), ("exchange_ms", C.c_double), ("concat_ms", C.c_double),
+                ("device", C.c_int32 * MAX_FANOUT), ("blocks", C.c_uint32 * MAX_FANOUT), ("lane_frames", C.c_uint64 * MAX_FANOUT),
+                ("payload_bytes", C.c_uint64 * MAX_FANOUT), ("encode_ms", C.c_double * MAX_FANOUT)]
+
+
+def fanout_range(nblocks: int, nlanes: int, lane: int):
+    """(first block, block count) of lane `lane` of `nlanes` over a stream of `nblocks` blocks."""
+    a, b = C.c_uint32(), C.c_uint32()
+    lib().lacx_fanout_range(C.c_uint32(nblocks), C.c_uint32(nlanes), C.c_uint32(lane), C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 PCM_PLANAR_I32, PCM_INTERLEAVED_I16, PCM_INTERLEAVED_I24 = 0, 1, 2

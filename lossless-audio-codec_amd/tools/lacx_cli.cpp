@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
     cfg.stereo_mode = info.channels == 1 ? 0 : stereo_mode;
     cfg.zero_run_enabled = 1;
     cfg.partitioning_enabled = partitioning ? 1 : 0;
-    cfg.device = -1;
+    cfg.device = LACX_DEVICE_ALL;  // every visible device: the blocks fan out over them (the reference spreads them over its threads)
     cfg.emit_threads = (uint32_t)(threads > 0xFFFFFFFFull ? 0xFFFFFFFFull : threads);
     lacx_encoder* enc = nullptr;
     if (lacx_encoder_create(&cfg, &enc) != LACX_OK) {

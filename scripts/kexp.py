@@ -1,5 +1,5 @@
 """Diagnostic A/B harness (not part of the default suite): times the device-resident encode of one workload with
-differently built libraries, one child process per library (LACX_LIB_OVERRIDE), and checks the bytes against the golden
+differently built libraries, one child process per library (KEXP_LIB -> lacx.use_library), and checks the bytes against the golden
 digest where one exists.  usage: kexp.py <lib.so>[,<lib.so>...] [seconds=600] [kind=music] [bit_depth=16] [rate=48000]
 A library whose name contains "stamps" also prints the in-kernel phase stamps (scripts/stamps.py)."""
 import hashlib, json, os, subprocess, sys, time
@@ -14,6 +14,7 @@ def child(secs, kind, bd, sr):
     import __graft_entry__ as ge
     pkg = ge.load_pkg()
     lacx, synth = pkg.lacx, pkg.synth
+    lacx.use_library(os.environ["KEXP_LIB"])
     frames = secs * sr
     seed, stereo = (2026, "wide") if kind == "music" else ((7, "wide") if kind == "mixed" else (3, "independent"))
     L, R = synth.synth_pcm(frames, 2, bd, sr, seed=seed, kind=kind, stereo=stereo)
@@ -53,7 +54,7 @@ def child(secs, kind, bd, sr):
     ent = dg.get((frames, bd, sr, kind, seed))
     ok = None if ent is None else (ent["lac_sha256"] == sha)
     print(f"RESULT full_ms min {min(full):.4f} med {sorted(full)[5]:.4f}  step_ms min {min(step):.3f} med {sorted(step)[5]:.3f}  digest {ok}", flush=True)
-    if "stamps" in os.environ.get("LACX_LIB_OVERRIDE", ""):
+    if "stamps" in os.environ.get("KEXP_LIB", ""):
         import ctypes as C
         buf = (C.c_ulonglong * 40)()
         lacx.lib().lacx_debug_stamps(buf)
@@ -74,7 +75,7 @@ if __name__ == "__main__":
     libs = sys.argv[1].split(",")
     rest = sys.argv[2:] + ["600", "music", "16", "48000"][len(sys.argv) - 2:]
     for lib in libs:
-        env = dict(os.environ, KEXP_CHILD="1", LACX_LIB_OVERRIDE=os.path.join(ROOT, lib))
+        env = dict(os.environ, KEXP_CHILD="1", KEXP_LIB=os.path.join(ROOT, lib))
         print(f"== {lib} {' '.join(rest)}", flush=True)
         p = subprocess.run([sys.executable, os.path.abspath(__file__)] + rest, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         print("\n".join(l for l in p.stdout.splitlines() if l.startswith("RESULT") or l.startswith("  ")) or p.stdout[-2000:], flush=True)

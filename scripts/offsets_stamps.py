@@ -4,7 +4,6 @@ barrier passed, stores issued -- and the host-visible tail time.  usage: offsets
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("LACX_LIB_OVERRIDE", os.path.join(ROOT, "exp", "liblacx_stamps.so"))
 if len(sys.argv) > 1 and sys.argv[1] == "direct":
     os.environ["LACX_DIRECT_PACKER"] = "1"
 import numpy as np
@@ -12,6 +11,7 @@ import torch
 import __graft_entry__ as ge
 pkg = ge.load_pkg()
 lacx, synth = pkg.lacx, pkg.synth
+lacx.use_library(os.path.join(ROOT, "exp", "liblacx_stamps.so"))
 L, R = synth.synth_pcm(600 * 48000, 2, 16, 48000, seed=2026, kind="music", stereo="wide")
 d = torch.from_numpy(synth.interleave(L, R, 16).view(np.int16)).cuda()
 enc = lacx.Encoder(12, 2, 48000, 16, device=0)

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "codec/block/encoder.hpp"
@@ -27,7 +28,66 @@ static bool throws(F&& f) {
     return false;
 }
 
-int main() {
+// LAC::Encoder over several devices (ref src/codec/lac/encoder.cpp:385-465 spreads the blocks over its workers itself):
+// the default (every visible device), explicit lists with repeated ordinals, set_thread_count untouched -- same bytes.
+static int fanout_checks() {
+    const size_t frames = 16384 * 9 + 4321;
+    std::vector<int32_t> left(frames), right(frames);
+    uint32_t s = 12345;
+    int32_t a = 0, b = 0;
+    for (size_t i = 0; i < frames; ++i) {
+        s = s * 1664525u + 1013904223u;
+        a += (int32_t)((s >> 20) & 0xFF) - 128;
+        b += (int32_t)((s >> 8) & 0x7F) - 64;
+        if (a > 30000 || a < -30000) a = 0;
+        if (b > 30000 || b < -30000) b = 0;
+        left[i] = a;
+        right[i] = (i / 40000) % 2 ? b : a / 2;
+    }
+    LAC::Encoder one(12, 2, 48000, 16);
+    one.set_devices({0});
+    const std::vector<uint8_t> want = one.encode(left, right);
+    CHECK(want.size() > 22);
+    LAC::Encoder all(12, 2, 48000, 16);  // default: every visible device
+    CHECK(all.encode(left, right) == want);
+    for (const std::vector<int>& list : {std::vector<int>{0, 0}, std::vector<int>{0, 0, 0, 0}, std::vector<int>{0, 0, 0, 0, 0, 0, 0}}) {
+        LAC::Encoder e(12, 2, 48000, 16);
+        e.set_devices(list, 1);
+        LAC::ThreadCollector tc;
+        CHECK(e.encode(left, right, &tc) == want);
+        CHECK(e.encode(left, right) == want);  // and again on the same handle
+        LAC::Encoder copy = e;                 // a copy keeps the list
+        CHECK(copy.encode(left, right) == want);
+    }
+    const int n = lacx_device_count();
+    if (n > 1) {
+        std::vector<int> list;
+        for (int i = 0; i < n; ++i) list.push_back(i);
+        LAC::Encoder e(12, 2, 48000, 16);
+        e.set_devices(list, 1);
+        CHECK(e.encode(left, right) == want);
+    }
+    {   // errors keep the reference's wording and the stream-wide index
+        std::vector<int32_t> l2 = left;
+        l2[16384 * 7 + 3] = 40000;
+        LAC::Encoder e(12, 2, 48000, 16);
+        e.set_devices({0, 0, 0}, 1);
+        bool ok = false;
+        try { e.encode(l2, right); } catch (const std::invalid_argument& ex) {
+            ok = std::string(ex.what()) == "left sample at index " + std::to_string(16384 * 7 + 3) + " is outside the configured PCM bit depth";
+        }
+        CHECK(ok);
+    }
+    LAC::Decoder dec;
+    std::vector<int32_t> ol, orr;
+    dec.decode(want.data(), want.size(), ol, orr);
+    CHECK(ol == left && orr == right);
+    std::printf("mirror api (fan-out): %s\n", fails ? "FAILED" : "ok");
+    return fails ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "fanout") return fanout_checks();
     std::vector<int32_t> left(3000), right(3000);
     for (size_t i = 0; i < left.size(); ++i) { left[i] = (int32_t)((i * 37) % 2000) - 1000; right[i] = left[i] / 2; }
     // argument validation (ref src/codec/lac/encoder.cpp:220-237)

@@ -547,6 +547,7 @@ def test_pinned_reservation_regrows(gpu, oracle, monkeypatch):
     payload, table = enc.encode_shard(left, right)
     assert gpu.lacx.assemble(48000, 16, 2, 2, [(payload, table)]) == want
     monkeypatch.delenv("LACX_PINNED_CAP_BYTES")
+    enc = gpu.lacx.Encoder(12, 2, 48000, 16, device=0)  # (knobs are read when the encoder is created)
     assert enc.encode(left, right) == want
     assert enc.timing().regrows == 0
 
@@ -581,16 +582,17 @@ def test_host_emit_waits_for_the_callers_stream(gpu, oracle):
 
 @pytest.mark.parametrize("mode", ["fused", "k_emit_only", "every_fifth_left_to_k_emit", "packer_gives_up",
                                   "packer_16_waves", "packer_48_waves"])
-def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
+def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, request, mode):
     """The emit fused into the analysis kernel + the streaming packer beside it (default), k_offsets + k_emit alone,
     and the two repair paths: a test hook leaves every fifth channel block to k_emit, another one fills the staging
     slots but never announces them, so that the packer gives up and k_pack moves everything.  Same bytes every time."""
     if mode == "k_emit_only":
         monkeypatch.setenv("LACX_FUSED_EMIT", "0")
-    if mode == "every_fifth_left_to_k_emit":
-        monkeypatch.setenv("LACX_DEBUG_SKIP", "1024")
-    if mode == "packer_gives_up":
-        monkeypatch.setenv("LACX_DEBUG_SKIP", "8192")
+    if mode in ("every_fifth_left_to_k_emit", "packer_gives_up"):
+        # the hooks exist only in the diagnostic twin of the library (analysis kernel built with -DLACX_TEST_HOOKS)
+        gpu.lacx.use_library(gpu.lacx.HOOKS_LIB_PATH)
+        request.addfinalizer(lambda: gpu.lacx.use_library(None))
+        monkeypatch.setenv("LACX_DEBUG_SKIP", "1024" if mode == "every_fifth_left_to_k_emit" else "8192")
     if mode == "packer_16_waves":  # the packer's waves are independent: any number of them gives the same bytes
         monkeypatch.setenv("LACX_PACK_GRID", "1")
     if mode == "packer_48_waves":
@@ -608,6 +610,11 @@ def test_fused_emit_and_its_fallbacks(gpu, oracle, monkeypatch, mode):
             t = enc.timing()
             small_last = ch == 2 and sm == 2 and (frames % 16384) and (frames % 16384) <= 4096
             assert t.emit_direct == (-(-frames // 16384) - (1 if small_last else 0)) * ch
+        if mode == "every_fifth_left_to_k_emit":
+            assert 0 < enc.timing().emit_direct < -(-frames // 16384) * ch or frames < 16384 * 3
+        if mode == "packer_gives_up":
+            assert enc.timing().packer_gave_up > 0 and enc.timing().moved_by_k_pack > 0
+        enc.close()
 
 
 def test_batch_of_streams_is_one_job_with_the_same_bytes(gpu, oracle):
@@ -694,3 +701,71 @@ def test_block_encoder_full_int32_domain(gpu, oracle):
             assert got == want, (i, zr, pt, len(got), len(want))
     with pytest.raises(ValueError, match="larger than 16384"):
         be.encode(np.zeros(16385, np.int32))
+
+
+def test_one_handle_through_batch_shard_batch_wide_block(gpu, oracle):
+    """One encoder handle used for a batch, then a drained shard encode, then a larger batch (the descriptor table grows),
+    then a wide Block::Encoder block: the batch's growth path must leave the shard path's buffers and streams alone
+    (round-3 advisor finding: it freed them)."""
+    import torch
+
+    def stream(frames, seed, kind="mixed"):
+        left, right = gpu.synth.synth_pcm(frames, 2, 16, 48000, seed=seed, kind=kind)
+        inter = gpu.synth.interleave(left, right, 16)
+        return left, right, torch.from_numpy(inter.view(np.int16)).cuda()
+
+    a = [stream(16384 * 3 + 10 * i, 100 + i) for i in range(2)]
+    b = [stream(16384 * 2 + 7 * i, 200 + i) for i in range(40)]  # 40 streams: the descriptor table must grow
+    be = gpu.lacx.BatchEncoder([(48000, 16, 2)] * len(a), device=0)
+    enc = be._enc  # the handle under test
+
+    def check_batch(be_, set_):
+        res = be_.encode_device([(d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16, 2, l.size) for l, r, d in set_])
+        for (l, r, d), (pay, tab) in zip(set_, res):
+            assert gpu.lacx.assemble(48000, 16, 2, 2, [(pay.tobytes(), tab.copy())]) == oracle.encode(l, r, 48000, 16, 2, threads=8)
+
+    check_batch(be, a)
+    l, r, d = stream(16384 * 300 + 55, 300, "music")  # more than one packer range
+    want = oracle.encode(l, r, 48000, 16, 2, threads=8)
+    for _ in range(2):
+        pay, tab = enc.encode_shard_pcm_device_view(d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16, 2, l.size)
+        assert gpu.lacx.assemble(48000, 16, 2, 2, [(pay.tobytes(), np.array(tab, dtype=np.uint32))]) == want
+    be.formats = [(48000, 16, 2)] * len(b)
+    check_batch(be, b)
+    pay, tab = enc.encode_shard_pcm_device_view(d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16, 2, l.size)
+    assert gpu.lacx.assemble(48000, 16, 2, 2, [(pay.tobytes(), np.array(tab, dtype=np.uint32))]) == want
+    # a wide block on the same handle (lacx_block_encode's own scratch), before and after another batch
+    wide = (np.arange(5000, dtype=np.int64) * 1000003 % (1 << 31) - (1 << 30)).astype(np.int32)
+    import ctypes as C
+    for _ in range(2):
+        out, size = C.POINTER(C.c_uint8)(), C.c_uint64()
+        rc = gpu.lacx.lib().lacx_block_encode(enc._handle(), wide.ctypes.data_as(C.POINTER(C.c_int32)), C.c_uint32(wide.size),
+                                              C.byref(out), C.byref(size))
+        assert rc == 0
+        got = C.string_at(out, size.value)
+        gpu.lacx.lib().lacx_free(out)
+        assert got == oracle.block_encode(wide)
+        check_batch(be, b)
+
+
+def test_batch_regrows_instead_of_failing(gpu, oracle, monkeypatch):
+    """A stream of a batch that needs more than its estimated pinned region (forced tiny here) makes the job run once more
+    with exact regions -- the reference never fails on size, and neither does the shard path."""
+    import torch
+
+    monkeypatch.setenv("LACX_PINNED_CAP_BYTES", "20000")
+    specs = [(16384 * 3 + 500, 2, 16, 48000, 2, "noise"), (16384 * 2 + 77, 1, 24, 44100, 0, "noise"), (900, 2, 16, 96000, 2, "music")]
+    streams, keep, want = [], [], []
+    for i, (frames, ch, bd, sr, sm, kind) in enumerate(specs):
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=60 + i, kind=kind)
+        inter = gpu.synth.interleave(left, right, bd)
+        d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+        keep.append(d)
+        streams.append((d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24, ch, frames))
+        want.append(oracle.encode(left, right, sr, bd, sm, threads=8))
+    be = gpu.lacx.BatchEncoder([(sr, bd, sm) for (_, _, bd, sr, sm, _) in specs], device=0)
+    for _ in range(2):
+        res = be.encode_device(streams)
+        for (frames, ch, bd, sr, sm, _), (pay, tab), w in zip(specs, res, want):
+            assert gpu.lacx.assemble(sr, bd, sm, ch, [(pay.tobytes(), tab.copy())]) == w
+        assert be.timing().regrows == 1

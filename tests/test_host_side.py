@@ -183,3 +183,53 @@ def test_stream_parse_and_decode_without_a_device(pkg):
     if pkg.lacx.device_count() <= 0:
         with pytest.raises(RuntimeError, match="no usable HIP device"):
             pkg.lacx.decode(lac)
+
+
+def test_fanout_ranges_are_the_contiguous_block_split(pkg):
+    """lacx_fanout_range: lane g of G over B blocks = [g*B/G, (g+1)*B/G) -- contiguous, complete, sizes differ by at most one
+    (the reference's pool hands out single blocks, ref lac/encoder.cpp:404-435)."""
+    for nb in (1, 7, 64, 1758, 21094):
+        for lanes in (1, 2, 3, 4, 8, 16):
+            got = [pkg.lacx.fanout_range(nb, lanes, g) for g in range(lanes)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == nb
+            for (a, c), (a2, _) in zip(got[:-1], got[1:]):
+                assert a + c == a2
+            sizes = [c for _, c in got]
+            assert max(sizes) - min(sizes) <= 1
+    assert [pkg.lacx.fanout_range(21094, 8, g)[1] for g in range(8)] == [2636, 2637, 2637, 2637, 2636, 2637, 2637, 2637]
+
+
+def test_multi_device_encoder_without_a_device_fails_loudly(pkg):
+    """An encoder over a device list validates its arguments like a plain one and has no CPU path either."""
+    import ctypes as C
+
+    left, right = pkg.synth.synth_pcm(16384 * 3, 2, 16, 48000, seed=1, kind="music")
+    enc = pkg.lacx.Encoder(12, 2, 48000, 16, devices=[0, 0, 0], min_blocks_per_device=1)
+    assert enc.lanes() == 3
+    with pytest.raises(ValueError, match="left channel must not be empty"):
+        enc.encode(np.zeros(0, np.int32), None)
+    with pytest.raises(ValueError, match="unsupported sample rate"):
+        pkg.lacx.Encoder(12, 2, 12345, 16, devices=[0, 1]).encode(left, right)
+    if pkg.lacx.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            enc.encode(left, right)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            pkg.lacx.Encoder(12, 2, 48000, 16, device=pkg.lacx.DEVICE_ALL).encode(left, right)
+    # bad lists are refused at creation
+    L = pkg.lacx.lib()
+    h = C.c_void_p()
+    cfg = pkg.lacx.Config(48000, 16, 2, 1, 1, -1, 0, 0)
+    assert L.lacx_encoder_create_multi(C.byref(cfg), (C.c_int32 * 1)(-1), C.c_uint32(1), C.c_uint32(0), C.byref(h)) == pkg.lacx.E_INVALID
+    assert L.lacx_encoder_create_multi(C.byref(cfg), (C.c_int32 * 17)(*([0] * 17)), C.c_uint32(17), C.c_uint32(0), C.byref(h)) == pkg.lacx.E_INVALID
+    assert L.lacx_encoder_create_multi(C.byref(cfg), None, C.c_uint32(0), C.c_uint32(0), C.byref(h)) == pkg.lacx.E_INVALID
+
+
+def test_hooks_library_is_a_separate_build(pkg):
+    """The product library carries no test hook: LACX_DEBUG_SKIP only acts in liblacx_hooks.so (-DLACX_TEST_HOOKS), which
+    exports the same ABI."""
+    import ctypes as C
+
+    assert os.path.exists(pkg.lacx.HOOKS_LIB_PATH), "liblacx_hooks.so missing: make -C lossless-audio-codec_amd all"
+    hooks = C.CDLL(pkg.lacx.HOOKS_LIB_PATH)
+    for name in pkg.lacx.EXPORTS:
+        assert hasattr(hooks, name)
