@@ -109,7 +109,14 @@ typedef struct lacx_timing {
     uint32_t packer_gave_up;  /* packer waves that stopped after 20 ms without an awaited record (0 normally; when the
                                  packer cannot run beside the analysis -- a profiler that serialises kernels, a shared
                                  GPU -- every wave gives up and k_pack moves everything: correct, but slower) */
-    uint32_t reserved0;
+    uint32_t drain_copies;    /* copy-engine drain: range copies issued while the kernels ran (the tail copy not counted) */
+    /* The payload drain depends on the calling thread: it polls pinned progress words and issues a copy per completed
+       range.  These say how attentive it was (all in ms since the call began; 0 when the drain is not in use): */
+    double drain_first_ms;    /* first range copy issued */
+    double drain_last_ms;     /* last range copy issued */
+    double poll_gap_max_ms;   /* longest interval between two looks at the progress words (a descheduled or busy host thread) */
+    double kernels_done_ms;   /* the host saw the last kernel's completion word */
+    double enqueue_ms;        /* everything enqueued (the call's launch phase) */
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);

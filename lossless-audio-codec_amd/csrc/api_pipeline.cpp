@@ -422,6 +422,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         HIP_TRY(e, launch_gather(g, s), "gather launch");
         HIP_TRY(e, hipEventRecord(e->done[c], s), "event record");
     }
+    e->timing.enqueue_ms = ms_since(t0);
     e->pend.active = true;
     e->pend.nb = nb;
     e->pend.channels = channels;
@@ -494,6 +495,8 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     // Copy-engine drain: while the kernels run, every range of stream indices the packer reports complete is fetched
     // from the device payload into the pinned result buffer (hipMemcpyAsync on its own stream: a copy engine, not CUs).
     uint64_t drained_to = 0;
+    e->timing.drain_copies = 0;
+    e->timing.drain_first_ms = e->timing.drain_last_ms = e->timing.poll_gap_max_ms = e->timing.kernels_done_ms = 0;
     const bool dbg_drain = e->knobs.debug_drain;
     const bool two_streams = e->knobs.two_copy_streams;
     if (e->pend.drained) {
@@ -510,6 +513,10 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
                                        (next & 1u) && two_streams ? e->copy_stream2 : e->copy_stream) != hipSuccess)
                         return;  // (the final copy below fetches what is missing)
                     drained_to = end;
+                    const double now = ms_since(t0);
+                    if (e->timing.drain_copies == 0) e->timing.drain_first_ms = now;
+                    e->timing.drain_last_ms = now;
+                    e->timing.drain_copies += 1;
                 }
                 ++next;
             }
@@ -517,11 +524,28 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         // (no runtime call in the loop but the copies: the gather kernel -- the last one of the call -- stores the
         // cumulative byte count of the last chunk, non-zero, into pinned memory that was zeroed before the launch)
         const volatile unsigned long long* finished = &e->h_totals[chunks.size() - 1];
+        // The loop is a spin on pinned memory with a pause instruction between looks (a sibling hyper-thread keeps its
+        // issue slots); every look is time-stamped, so a host thread that was descheduled or busy elsewhere shows up as
+        // poll_gap_max_ms instead of as an unexplained long step.  Once a millisecond the last chunk's event is queried as
+        // well: a failed device ends the wait even though its completion word never arrives.
         const auto poll0 = clk::now();
+        auto last_look = poll0;
+        auto last_query = poll0;
         while (*finished == 0ull) {
             pump();
-            if (ms_since(poll0) > 20000.0) break;  // (a lost device: the event wait below reports it)
+            const auto now = clk::now();
+            const double gap = std::chrono::duration<double, std::milli>(now - last_look).count();
+            if (gap > e->timing.poll_gap_max_ms) e->timing.poll_gap_max_ms = gap;
+            last_look = now;
+            if (std::chrono::duration<double, std::milli>(now - last_query).count() > 1.0) {
+                last_query = now;
+                const hipError_t qe = hipEventQuery(e->done[chunks.size() - 1]);
+                if (qe != hipErrorNotReady) break;  // done (the word is about to follow) or failed: the event wait below reports it
+                if (std::chrono::duration<double, std::milli>(now - poll0).count() > 20000.0) break;
+            }
+            __builtin_ia32_pause();
         }
+        e->timing.kernels_done_ms = ms_since(t0);
         if (dbg_drain) std::fprintf(stderr, "[drain] kernels done at %.3f ms, copy stream %s\n", ms_since(t0),
                                     hipStreamQuery(e->copy_stream) == hipSuccess ? "idle" : "busy");
         pump();

@@ -86,7 +86,12 @@ class Timing(C.Structure):
         ("emit_direct", C.c_uint32),
         ("moved_by_k_pack", C.c_uint32),
         ("packer_gave_up", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("drain_copies", C.c_uint32),
+        ("drain_first_ms", C.c_double),
+        ("drain_last_ms", C.c_double),
+        ("poll_gap_max_ms", C.c_double),
+        ("kernels_done_ms", C.c_double),
+        ("enqueue_ms", C.c_double),
     ]
 
 
