@@ -37,6 +37,7 @@ Knobs read_knobs() {
     k.tune.persistent_grid = (uint32_t)num("LACX_PERSISTENT_GRID");
     k.tune.pack_nap = (int)num("LACX_PACK_NAP");
     k.tune.pack_grid = (int)num("LACX_PACK_GRID");
+    k.tune.no_pairs = set("LACX_NO_PAIRS");
     return k;
 }
 

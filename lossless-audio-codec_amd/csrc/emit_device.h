@@ -34,6 +34,58 @@ __device__ __forceinline__ void scan_nx_part2(M& sh, int tid, int32_t inc, const
 }
 
 
+// Walk 2 for the common shape of a channel block (device only): the whole bitstream fits ONE output tile (every 16-bit
+// block, most 24-bit ones), the lane's chunk is complete and lies inside one partition, and that partition is coded with
+// plain Rice tokens (mode 0 adaptive / 3 static) -- all of it for every lane of the wave, so the choice is one scalar
+// branch.  Against the general walk (emit_walk_t, which stays for everything else) this one carries no token grammar
+// selects, no zero-run look-ahead loads, no 64-bit word index and no tile bounds checks: per sample a shift, a mask, one
+// 64-bit funnel insert and, every other sample or so, one LDS word store.  A thread's tokens are one contiguous bit range:
+// its first and last word may hold a neighbour's bits (ds_or), the words in between are its own (plain store into the
+// zeroed tile).  `pos` = bit position of the thread's first token in the channel block (< 2^22).
+template <class G, class M>
+__device__ __forceinline__ void emit_walk2_rice(const Thread<G>& th, M& sh, uint32_t* __restrict__ words, uint32_t pos,
+                                                bool is_static, uint32_t k0) {
+    const int t = th.tid;
+    uint64_t acc = 0;              // pending bits, left-aligned
+    uint32_t fill = pos & 31u;     // number of pending bits (< 32 between samples)
+    uint32_t word = pos >> 5;
+    bool shared = true;            // the first word may also hold the previous thread's bits
+    auto put = [&](uint32_t value, uint32_t n) {  // n in 1..32, value < 2^n, MSB first
+        acc |= (uint64_t)value << (64u - fill - n);
+        fill += n;
+        if (fill >= 32u) {
+            const uint32_t w = (uint32_t)(acc >> 32);
+            if (shared) {
+                if (w) atomicOr(&words[word], w);
+            } else {
+                words[word] = w;
+            }
+            acc <<= 32;
+            fill -= 32u;
+            ++word;
+            shared = false;
+        }
+    };
+#pragma unroll 4
+    for (int i = 0; i < G::CH; ++i) {
+        const uint32_t u = sh.u[i * G::T + t] & 0x3FFFFFFFu;
+        const uint32_t k = is_static ? k0 : (uint32_t)sh.xp.o.kin[i * G::T + t];
+        uint32_t q = u >> k;
+        const uint32_t rem = u & ((1u << k) - 1u);  // k <= 31
+        if (q + k <= 30u) {  // the whole token in one insert of at most 31 bits
+            put((((1u << q) - 1u) << (k + 1u)) | rem, q + 1u + k);
+        } else {  // a long unary part (rare): 32 ones at a time, then the rest and the stop bit + remainder
+            while (q >= 32u) {
+                put(0xFFFFFFFFu, 32u);
+                q -= 32u;
+            }
+            if (q) put((1u << q) - 1u, q);
+            put(rem, k + 1u);
+        }
+    }
+    if (fill) atomicOr(&words[word], (uint32_t)(acc >> 32));  // the last, partial word is shared with the next thread
+}
+
 // Emit of one channel block from the residual in sh.u (plain zigzag values, block scans of tabP / tabNZ / tabNX done,
 // plan fields loaded): walk 1 (Rice parameter per sample + token bits), bit offsets, walk 2 into 48 KiB LDS tiles,
 // copy-out.  `resolve` is called once by all threads (it may contain barriers) before the first byte leaves the
@@ -99,7 +151,25 @@ __device__ __forceinline__ bool emit_body(M& sh, Thread<G>& th, uint32_t n, uint
         BitTile tile{sh.xp.o.obits, bit0, (uint32_t)kEmitTileWords};
         if (bit0 == 0) emit_header(th, sh, &tile, orw);
         const unsigned long long tile_end = bit0 + (unsigned long long)kEmitTileWords * 32u;
-        if (mypos < tile_end && mypos + mybits > bit0) {
+        // the lean walk where the whole bitstream is in this tile and the wave's chunks are plain Rice (see emit_walk2_rice)
+        bool lean = false;
+        uint32_t lean_k0 = 0;
+        bool lean_static = false;
+        if (bit0 == 0 && nbytes * 8u <= (unsigned long long)kEmitTileWords * 32u) {  // uniform
+            const uint32_t p = sh.p, parts = sh.parts;
+            const uint32_t pbase = p ? (n >> p) : n;
+            uint32_t part = p ? ((uint32_t)th.a / pbase) : 0u;
+            if (part >= parts) part = parts - 1u;
+            const uint32_t pend = (part + 1u == parts) ? n : (part + 1u) * pbase;
+            const uint32_t mk = sh.part_mode_k[part];
+            const uint32_t mode = mk >> 5;
+            lean_k0 = mk & 31u;
+            lean_static = mode == 3u;
+            lean = wave_all(th.cnt == G::CH && (uint32_t)th.a + (uint32_t)G::CH <= pend && (mode == 0u || mode == 3u) && lean_k0 <= 30u);
+        }
+        if (lean) {
+            emit_walk2_rice<G>(th, sh, sh.xp.o.obits, (uint32_t)mypos, lean_static, lean_k0);
+        } else if (mypos < tile_end && mypos + mybits > bit0) {
             if (narrow) {
                 emit_walk<G, true>(th, sh, &tile, mypos, orw, stw);
             } else {

@@ -51,10 +51,12 @@ __device__ unsigned long long g_stamp_acc[40];
 // Every wait of the packer is bounded; when it gives up, or for anything it did not move, k_pack / k_emit finish the
 // job after the analysis (they always run), so no dispatch order or co-residency is assumed for correctness.
 // ---------------------------------------------------------------------------------------------
-// A slot whose bitstream has been stored but not announced yet (persistent workgroups).
+// A slot whose bitstream has been stored but not announced yet (persistent workgroups).  Lives in LDS: only thread 0 ever
+// acts on it, and a struct handed down by pointer through the analysis is kept in scratch memory by the compiler (two
+// stores and four loads per slot and thread, a quarter of the kernel's scratch traffic).
 struct PendingSlot {
-    long long idx = -1;
-    bool done = false, silent = false;
+    long long idx;
+    uint32_t done, silent;
 };
 
 // idx: stream index of this channel block; flag_byte: the block's LR/MS flag byte precedes this channel block.
@@ -95,9 +97,11 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
     // workgroup does not wait here: it announces the slot behind the barrier that ends the staging of its next slot
     // (publish_pending), when the stores have long drained.
     if (defer) {
-        defer->idx = idx;
-        defer->done = done;
-        defer->silent = LACX_HOOK(prm, 8192u);
+        if (tid == 0) {
+            defer->idx = idx;
+            defer->done = done ? 1u : 0u;
+            defer->silent = LACX_HOOK(prm, 8192u) ? 1u : 0u;
+        }
         return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -112,11 +116,14 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
 // The announcement of a slot whose stores every wave of the workgroup has drained (s_waitcnt vmcnt(0)) before the barrier
 // the caller has just passed.
 __device__ __forceinline__ void publish_pending(const FuseArgs& fa, PendingSlot& pend, int tid) {
-    if (pend.idx >= 0 && tid == 0) {
-        if (pend.done) fa.emitted[pend.idx] = 2u;
-        if (!pend.silent) rec_store(&fa.ready_rec[pend.idx], pend.done ? 1ull : 2ull);
+    if (tid == 0) {
+        const long long idx = pend.idx;
+        if (idx >= 0) {
+            if (pend.done) fa.emitted[idx] = 2u;
+            if (!pend.silent) rec_store(&fa.ready_rec[idx], pend.done ? 1ull : 2ull);
+        }
+        pend.idx = -1;
     }
-    pend.idx = -1;
 }
 
 // Candidate scoring (ref block/encoder.cpp:337-359) by the 64 lanes of one wave; same result as score_candidate() of
@@ -211,7 +218,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         sh.best_cand = -1;
         sh.tabUZ[G::T] = sh.tabUZ[G::T + 1] = 0;  // "not a zero" past the slot (phase_b_quick)
     }
-    if (pend && pend->idx >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (uniform) the previous slot's stores
+    if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous slot's stores (long drained; free when there are none)
     __syncthreads();
     if (pend) publish_pending(fuse, *pend, tid);
     STAMP(0);
@@ -221,7 +228,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     // stored, no barrier between candidates (ref block/encoder.cpp:362-407 walks them one by one).  Per candidate the
     // thread holds the sum of its leading-bit counts and a 2-bit code per position (zero / four / other) that is counted
     // once per chunk.
-    {
+    auto run_pass1 = [&](const bool real) {
         // Optimisation barrier on the chunk origin: without it the compiler hoists a dozen loop-invariant LDS
         // addresses and masks derived from it and, at the 128-VGPR budget, spills them to scratch.
         asm volatile("" : "+v"(th.a));
@@ -239,7 +246,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             const uint32_t g2 = wave_sum_u32(lo | (hi << 16));
             const uint32_t cnt0 = wave_sum_u32(bound_counts<G::CH>(b0));
             const uint32_t cnt1 = two ? wave_sum_u32(bound_counts<G::CH>(b1)) : 0u;
-            if ((tid & 63) == 0) {
+            if ((tid & 63) == 0 && real) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (h == 0 || two) {
@@ -271,8 +278,20 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             reduce_pair(8, bl[2], true, bl[3]);
             reduce_pair(10, bl[4], false, bl[4]);
         }
+    };
+#if defined(LACX_STAMPS) && LACX_STAMPS == 3
+    {   // diagnostic: the same pass (the same code) twice in a row -- the second trip finds it in the instruction cache
+        uint32_t trips = 2;
+        asm volatile("" : "+s"(trips));
+        for (uint32_t r = 0; r < trips; ++r) {
+            run_pass1(r == 0);
+            if (r == 0) STAMP(2); else STAMP(15);
+        }
     }
+#else
+    run_pass1(true);
     STAMP(2);
+#endif
     __syncthreads();
     if (tid <= 10) {
         // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
@@ -624,7 +643,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid, pend STAMP_ARGS);  // uniform
     }
     STAMP(23);
-#if defined(LACX_STAMPS) && LACX_STAMPS == 1
+#if defined(LACX_STAMPS) && (LACX_STAMPS == 1 || LACX_STAMPS == 3)
     // one wave per workgroup reports (a different one from workgroup to workgroup): with every wave adding its 24
     // sums to the same addresses the atomics themselves slowed every global load in the kernel down severalfold
     if ((tid & 63) == 0 && (tid >> 6) == (int)(blockIdx.x & 15u) && G::T == 1024) {
@@ -638,16 +657,20 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 // (At 127 VGPRs x 4 waves per SIMD an analysis workgroup fills the register files of its CU, so every workgroup of the
 // streaming packer takes a whole CU away from the analysis: measured +25 us of kernel time per packer workgroup, hence
 // the packer's small grid.  The compiler offers no way to cap this kernel at 120.)
+#ifndef LACX_PROBE_WAVES
+#define LACX_PROBE_WAVES 6
+#endif
 template <class G>
-__global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
+__global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans,
                                                   unsigned long long* __restrict__ t_first,
                                                   unsigned long long* __restrict__ t_last, FuseArgs fuse,
-                                                  uint32_t* __restrict__ work_ctr, uint32_t total_wg) {
+                                                  uint32_t* __restrict__ work_ctr, uint32_t total_wg, uint32_t pair_blocks) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ uint32_t s_next;
+    __shared__ PendingSlot s_pend;
     const int tid = threadIdx.x;
     // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
     if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -661,10 +684,18 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
     // sibling's L2 hit is worth.  Dynamic, so the workgroups that find no free CU while the packer holds its three simply
     // find no work left when they start.
     const bool persistent = work_ctr != nullptr;  // (uniform)
+    // Work units of the persistent form over ONE stereo stream (pair_blocks > 0): unit v < pair_blocks is BLOCK v -- the
+    // workgroup analyses its two channel slots one after the other, so the block's PCM comes from HBM once (the second
+    // staging hits the L2 / TCP of the same CU) instead of once per XCD that happens to draw one of its slots; the last
+    // blocks of the stream are handed out slot by slot (units pair_blocks ..), so that the tail of the kernel is balanced
+    // in single slots as before.
+    uint32_t rep = 0;         // channel slot of a pair unit
     uint32_t v = blockIdx.x;  // virtual workgroup id
-    PendingSlot pend;
     if (persistent) {
-        if (tid == 0) s_next = atomicAdd(work_ctr, 1u);
+        if (tid == 0) {
+            s_next = atomicAdd(work_ctr, 1u);
+            s_pend.idx = -1;
+        }
         __syncthreads();
         v = s_next;
     }
@@ -676,6 +707,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
         // class: 12 slots per block, skipped unless the block is uncertain.  which_base != 0: the two extra workgroups of
         // ONE block (global block one_block) whose four channels are all needed.
         uint32_t blk;  // global block of the launch set
+        uint32_t reps = 1u;  // slots this unit consists of
         int slot = -1;
         int which_in_block = -1;   // position of the slot among the block's needed whole-block slots
         uint32_t needed_slots = 0;
@@ -691,6 +723,19 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
                 blk = one_block;
                 sd = stream_of_block_uniform(br, blk);
                 wsel = v;
+            } else if (persistent && pair_blocks != 0u) {  // (one stream: the descriptor is in the kernel arguments)
+                sd = br.single;
+                uint32_t lblk;
+                if (v < pair_blocks) {
+                    lblk = v;
+                    wsel = rep;
+                    reps = 2u;
+                } else {
+                    const uint32_t s = v - pair_blocks;
+                    lblk = pair_blocks + (s >> 1);
+                    wsel = s & 1u;
+                }
+                blk = sd.first_block + lblk;
             } else {
                 sd = stream_of_workgroup(br, v);
                 const uint32_t per = sd.prm.channels == 2 ? 2u : 1u;
@@ -736,19 +781,21 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? 6 : 4) void k_analyze(BatchRef b
             int slot_tid = tid;
             asm volatile("" : "+v"(slot_tid));
             analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], slot_tid, fuse, fuse_idx, flag_byte,
-                            (uint32_t)((slot & 3) >= 2 ? 1u : 0u), persistent ? &pend : nullptr);
+                            (uint32_t)((slot & 3) >= 2 ? 1u : 0u), persistent ? &s_pend : nullptr);
             if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
         }
         if (!persistent) break;
         __syncthreads();  // every wave is done with this slot's LDS image (the emit's tile aliases the next staging area)
+        if (++rep < reps) continue;  // (uniform) the block's other channel slot
+        rep = 0;
         if (tid == 0) s_next = atomicAdd(work_ctr, 1u);
         __syncthreads();
         v = s_next;
     }
-    if (pend.idx >= 0) {  // (uniform) the last slot of a persistent workgroup
+    if (persistent) {  // the last slot of a persistent workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        publish_pending(fuse, pend, tid);
+        publish_pending(fuse, s_pend, tid);
     }
 }
 
@@ -839,7 +886,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     if (any_auto) {
         hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, br, 1, 0u, 0,
                            ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
-                           (uint32_t*)nullptr, 0u);
+                           (uint32_t*)nullptr, 0u, 0u);
         hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
                            ws.need_full, ws.plans);
     }
@@ -853,10 +900,16 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     // find its CUs taken wait, start when the others have left, find no work and leave.
     const bool persistent = analysis_is_persistent(ws);
     const uint32_t pgrid = tune.persistent_grid ? tune.persistent_grid : compute_units();
-    const uint32_t grid = persistent ? (total_wg < pgrid ? total_wg : pgrid) : total_wg;
+    // pair units (see k_analyze): one stereo stream, all blocks but the last `pgrid` (those go out slot by slot)
+    uint32_t pair_blocks = 0, units = total_wg;
+    if (persistent && !tune.no_pairs && br.table == nullptr && ls.nstreams == 1 && ls.streams[0].prm.channels == 2 && nb > pgrid) {
+        pair_blocks = nb - pgrid;
+        units = pair_blocks + 2u * (nb - pair_blocks);
+    }
+    const uint32_t grid = persistent ? (units < pgrid ? units : pgrid) : total_wg;
     hipLaunchKernelGGL(k_analyze<GFull>, dim3(grid), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
                        ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa, persistent ? ws.work_ctr : (uint32_t*)nullptr,
-                       total_wg);
+                       units, pair_blocks);
     if (any_both) {  // the 3rd and 4th slots of such a final block: a two-workgroup launch each
         for (uint32_t i = 0; i < ls.nstreams; ++i) {
             const StreamDesc& sd = ls.streams[i];
@@ -864,7 +917,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
             if (p.channels == 2 && p.stereo_mode == 2 && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit)
                 hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0,
                                    sd.first_block + p.num_blocks - 1u, 2, ws.lpcs, ws.need_full, ws.plans,
-                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{}, (uint32_t*)nullptr, 0u);
+                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{}, (uint32_t*)nullptr, 0u, 0u);
         }
     }
     if (ev) (void)hipEventRecord(ev[3], stream);

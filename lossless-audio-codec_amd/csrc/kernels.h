@@ -50,6 +50,7 @@ struct LaunchTuning {
     uint32_t persistent_grid = 0;  // workgroups of the persistent whole-block analysis (0 = one per CU)
     int pack_nap = 0;              // the streaming packer's polling pause (0 = default)
     int pack_grid = 0;             // the streaming packer's workgroups (0 = default)
+    bool no_pairs = false;         // persistent analysis: hand every slot out singly (LACX_NO_PAIRS; A/B of the pair units)
 };
 
 // Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while

@@ -36,13 +36,16 @@ def child(secs, kind, bd, sr):
     for _ in range(3):
         once()
     torch.cuda.synchronize()
-    full, step = [], []
+    full, step, probe, ingest = [], [], [], []
     res = None
     for _ in range(10):
         t0 = time.perf_counter()
         res = once()
         step.append((time.perf_counter() - t0) * 1e3)
-        full.append(enc.timing().full_ms)
+        tm = enc.timing()
+        full.append(tm.full_ms)
+        probe.append(tm.probe_ms)
+        ingest.append(tm.ingest_ms)
     sha = None
     if res is not None:
         pay, tab = res
@@ -53,7 +56,7 @@ def child(secs, kind, bd, sr):
               if e["gen"]["channels"] == 2 and e["stereo_mode"] == 2 and e["gen"].get("start", 0) == 0}
     ent = dg.get((frames, bd, sr, kind, seed))
     ok = None if ent is None else (ent["lac_sha256"] == sha)
-    print(f"RESULT full_ms min {min(full):.4f} med {sorted(full)[5]:.4f}  step_ms min {min(step):.3f} med {sorted(step)[5]:.3f}  digest {ok}", flush=True)
+    print(f"RESULT full_ms min {min(full):.4f} med {sorted(full)[5]:.4f}  step_ms min {min(step):.3f} med {sorted(step)[5]:.3f}  probe_ms med {sorted(probe)[5]:.4f} ingest_ms med {sorted(ingest)[5]:.4f}  digest {ok}", flush=True)
     if "stamps" in os.environ.get("KEXP_LIB", ""):
         import ctypes as C
         buf = (C.c_ulonglong * 40)()
