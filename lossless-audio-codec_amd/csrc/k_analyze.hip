@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t initial_k_wave(const uint32_t* planes256, ui
 template <class G>
 __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const AnalyzeParams& prm, uint32_t n_in,
                                              const SlotSrc& src, int64_t start, const LpcSet* __restrict__ lpc_slot,
-                                             ChannelPlan* __restrict__ plan_out, const int tid, const FuseArgs& fuse,
+                                             ChannelPlan* __restrict__ plan_out, int tid, const FuseArgs& fuse,
                                              const long long fuse_idx, const bool fuse_flag_byte,
                                              const uint32_t fuse_flag_value, PendingSlot* pend) {
     Smem<G>& sh = *reinterpret_cast<Smem<G>*>(smem_raw);
@@ -313,6 +313,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     uint32_t tried = 0;      // candidates already evaluated (uniform)
     int parity = 0;
     for (;;) {
+        // (an opaque thread index per trip and again behind the loop: comparisons and addresses derived from it are loop
+        // invariant, so the compiler computes them all in front of the loop -- two dozen lane masks and a handful of
+        // addresses -- and, with nowhere to keep them, parks them in spill lanes and scratch memory across the search)
+        asm volatile("" : "+v"(tid));
         if (tid < 64) {  // wave 0
             if (pending >= 0) {
                 // previous candidate's totals sit in the other buffers: score it, then clear them
@@ -451,6 +455,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     }
 
     STAMP(15);
+    asm volatile("" : "+v"(tid), "+v"(th.tid), "+v"(th.a));
     // ---- partition search on the winning residual -------------------------------------------
     const int best = sh.best_cand;
     int max_p = 0;
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_ana
             s_pend.idx = -1;
         }
         __syncthreads();
-        v = s_next;
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);  // (uniform: into a scalar register, and with it everything derived from it)
     }
     for (;;) {
         if (persistent && v >= total_wg) break;
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_ana
             blk = v / 12u;
             sd = stream_of_block_uniform(br, blk);
             const int s = 4 + (int)(v % 12u);
-            if ((need[blk] >> s) & 1u) slot = s;
+            if (((uint32_t)__builtin_amdgcn_readfirstlane((int)need[blk]) >> s) & 1u) slot = s;
         } else {
             uint32_t wsel;
             if (which_base) {
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_ana
             }
             int which = (int)wsel + which_base;
             which_in_block = which;
-            uint32_t m = need[blk] & 0xFu;
+            uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)need[blk]) & 0xFu;
             needed_slots = (uint32_t)__popc(m);
             while (m) {
                 const int s = __ffs((int)m) - 1;
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_ana
         rep = 0;
         if (tid == 0) s_next = atomicAdd(work_ctr, 1u);
         __syncthreads();
-        v = s_next;
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
     }
     if (persistent) {  // the last slot of a persistent workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
