@@ -328,6 +328,14 @@ int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out);
 int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
                 float* device_ms);
 const char* lacx_decode_last_error(void); /* of the calling thread */
+/* The same through a decoder object (ref LAC::Decoder, src/codec/lac/decoder.hpp:10-24) whose device buffers, stream and
+ * events live from call to call; lacx_decode keeps one such object per calling thread and device.  device = -1: the device
+ * that is current at the first call. */
+typedef struct lacx_decoder lacx_decoder;
+int lacx_decoder_create(int device, lacx_decoder** out);
+void lacx_decoder_destroy(lacx_decoder* dec);
+int lacx_decoder_decode(lacx_decoder* dec, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
+                        float* device_ms);
 
 /* Block::Encoder::encode drop-in for one channel block of n <= 16384 samples of ANY int32 value: blocks inside the 25-bit
  * mid/side domain of validated 16 / 24-bit input run on the streaming kernels, wider ones on a kernel of their own that

@@ -28,6 +28,7 @@ Knobs read_knobs() {
     k.persistent = !set("LACX_NO_PERSISTENT");
     k.debug_drain = set("LACX_DEBUG_DRAIN");
     k.two_copy_streams = !set("LACX_ONE_COPY_STREAM");
+    k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
     k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
     k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");
     k.pipe_chunks = (uint32_t)num("LACX_PIPE_CHUNKS");
@@ -338,7 +339,7 @@ std::vector<Chunk> plan_chunks(const Knobs& kn, uint32_t nb, bool device_emit, b
     const char* split_env = kn.pipe_split.empty() ? nullptr : kn.pipe_split.c_str();  // tuning knob: relative chunk sizes, e.g. "5,3,1"
     // Device emit: three chunks on three streams of falling priority, the last one a little smaller -- its
     // emit is the only one whose PCIe writes are not hidden under another chunk's analysis (measured best).
-    if (!split_env && !forced && device_emit && nchunks == 3u) split_env = (fused && upload) ? "1,3,4" : "5,5,4";
+    if (!split_env && !forced && device_emit && nchunks == 3u) split_env = (fused && upload) ? "1,2,3" : "5,5,4";
     if (const char* env = split_env) {
         std::vector<double> w;
         double sum = 0;
@@ -508,6 +509,7 @@ int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out) {
 void lacx_encoder_destroy(lacx_encoder* e) {
     if (!e) return;
     destroy_fanout(e);  // the lanes' threads, communicators and child encoders first
+    e->uploader.reset();
     e->pool.reset();
     std::free(e->view_buf);
     std::free(e->view_table);
@@ -539,6 +541,10 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->h_err) (void)hipHostFree(e->h_err);
         if (e->h_emitted) (void)hipHostFree(e->h_emitted);
         if (e->h_tspan) (void)hipHostFree(e->h_tspan);
+        if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
+        if (e->front_stream) (void)hipStreamDestroy(e->front_stream);
+        for (auto& ev : e->up_ev)
+            if (ev) (void)hipEventDestroy(ev);
         if (e->h_range) (void)hipHostFree(e->h_range);
         if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
         if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);

@@ -66,8 +66,71 @@ int lacx_stream_parse(const uint8_t* lac, uint64_t size, lacx_stream_info* out) 
     return LACX_OK;
 }
 
-int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
-                float* device_ms) {
+// The decoder object: device buffers, a stream and two events that live from call to call (grow-only), so that a decode
+// costs its copies and its kernel, not six allocations (ref LAC::Decoder is an object too, src/codec/lac/decoder.hpp:10-24).
+struct lacx_decoder {
+    int device = -1;  // -1: whatever device is current at the first call
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint8_t* d_pay = nullptr;
+    uint64_t pay_cap = 0;
+    unsigned long long* d_offs = nullptr;
+    uint64_t offs_cap = 0;
+    int32_t *d_left = nullptr, *d_right = nullptr;
+    uint64_t pcm_cap = 0;
+    uint32_t* d_status = nullptr;
+    uint8_t* d_ms = nullptr;
+    uint32_t* h_status = nullptr;          // pinned
+    unsigned long long* h_offs = nullptr;  // pinned
+    uint32_t blocks_cap = 0;
+    std::string err;
+};
+
+namespace {
+void decoder_release(lacx_decoder* d) {
+    if (d->ready) (void)hipSetDevice(d->device);
+    if (d->e0) (void)hipEventDestroy(d->e0);
+    if (d->e1) (void)hipEventDestroy(d->e1);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->d_pay) (void)hipFree(d->d_pay);
+    if (d->d_offs) (void)hipFree(d->d_offs);
+    if (d->d_left) (void)hipFree(d->d_left);
+    if (d->d_right) (void)hipFree(d->d_right);
+    if (d->d_status) (void)hipFree(d->d_status);
+    if (d->d_ms) (void)hipFree(d->d_ms);
+    if (d->h_status) (void)hipHostFree(d->h_status);
+    if (d->h_offs) (void)hipHostFree(d->h_offs);
+    *d = lacx_decoder{};
+}
+// lacx_decode (no handle): one decoder per device for the life of the process (never freed: releasing device memory from
+// a static or thread-local destructor would race the HIP runtime's own shutdown), calls on one device take turns
+struct SharedDecoder {
+    std::mutex mu;
+    lacx_decoder dec;
+};
+constexpr int kMaxDecodeDevices = 64;
+std::mutex g_shared_mu;
+SharedDecoder* g_shared[kMaxDecodeDevices] = {};
+}  // namespace
+
+int lacx_decoder_create(int device, lacx_decoder** out) {
+    if (!out) return LACX_E_INVALID;
+    lacx_decoder* d = new lacx_decoder();
+    d->device = device;
+    *out = d;
+    return LACX_OK;
+}
+
+void lacx_decoder_destroy(lacx_decoder* d) {
+    if (!d) return;
+    decoder_release(d);
+    delete d;
+}
+
+int lacx_decoder_decode(lacx_decoder* d, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
+                        float* device_ms) {
+    if (!d) return decode_fail(LACX_E_INVALID, "null decoder");
     lacx_stream_info info;
     const int prc = lacx_stream_parse(lac, size, &info);
     if (prc) return prc;
@@ -88,71 +151,125 @@ int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, in
     const bool v2 = info.version == 2;
     const uint64_t entry = v2 ? 4u : 8u;
     const uint64_t head = 14 + entry * nb, pay = size - head;
-    std::vector<unsigned long long> offs(2 * ((size_t)nb + 1));  // byte offsets, then frame offsets
-    unsigned long long* byte_off = offs.data();
-    unsigned long long* frame_off = offs.data() + nb + 1;
-    byte_off[0] = frame_off[0] = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
-        frame_off[b + 1] = frame_off[b] + be32(lac + 14 + entry * b);
-        byte_off[b + 1] = v2 ? 0 : byte_off[b] + be32(lac + 18 + 8ull * b);
-    }
-    uint8_t* d_pay = nullptr;
-    unsigned long long* d_offs = nullptr;
-    int32_t *d_left = nullptr, *d_right = nullptr;
-    uint32_t* d_status = nullptr;
-    uint8_t* d_ms = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<uint32_t> status(nb);
+    const size_t noffs = 2 * ((size_t)nb + 1);  // byte offsets, then frame offsets
     int prev_device = -1;  // the caller's current device is put back on the way out
-    if (device >= 0) {
-        DEC_TRY(hipGetDevice(&prev_device), "hipGetDevice");
-        if (prev_device == device) prev_device = -1;
-        else DEC_TRY(hipSetDevice(device), "hipSetDevice");
+    if (!d->ready) {
+        if (d->device < 0) DEC_TRY(hipGetDevice(&d->device), "hipGetDevice");
     }
-    DEC_TRY(hipMalloc((void**)&d_pay, pay + kDecodeTailPad), "hipMalloc(payload)");  // the bit reader's look-ahead (decode.hip)
-    DEC_TRY(hipMemset(d_pay + pay, 0, kDecodeTailPad), "memset");
-    DEC_TRY(hipMemcpy(d_pay, lac + head, pay, hipMemcpyHostToDevice), "H2D payload");
-    DEC_TRY(hipMalloc((void**)&d_offs, offs.size() * sizeof(unsigned long long)), "hipMalloc(offsets)");
-    DEC_TRY(hipMemcpy(d_offs, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "H2D offsets");
-    DEC_TRY(hipMalloc((void**)&d_left, frames * sizeof(int32_t)), "hipMalloc(left)");
-    if (info.channels == 2) DEC_TRY(hipMalloc((void**)&d_right, frames * sizeof(int32_t)), "hipMalloc(right)");
-    DEC_TRY(hipMalloc((void**)&d_status, (size_t)nb * sizeof(uint32_t)), "hipMalloc(status)");
-    DEC_TRY(hipMalloc((void**)&d_ms, nb), "hipMalloc(flags)");
-    DEC_TRY(hipEventCreate(&e0), "hipEventCreate");
-    DEC_TRY(hipEventCreate(&e1), "hipEventCreate");
-    DEC_TRY(hipEventRecord(e0, nullptr), "event record");
-    if (v2)
-        DEC_TRY(launch_decode_serial(nb, info.channels, info.stereo_mode, info.bit_depth, d_pay, (uint32_t)(8ull * pay), d_offs + nb + 1,
-                                     d_left, d_right, d_status, d_ms, nullptr), "decode launch");
-    else
-        DEC_TRY(launch_decode(nb, info.channels, info.stereo_mode, info.bit_depth, d_pay, d_offs, d_offs + nb + 1, d_left, d_right,
-                              d_status, d_ms, nullptr), "decode launch");
-    DEC_TRY(hipEventRecord(e1, nullptr), "event record");
-    DEC_TRY(hipMemcpy(status.data(), d_status, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H status");
-    if (device_ms) (void)hipEventElapsedTime(device_ms, e0, e1);
-    for (uint32_t b = 0; b < nb; ++b) {
-        if (status[b]) {  // the first failing block, like the reference's message (lac/decoder.cpp:24-32)
-            static const char* const kWhat[] = {"", "block header", "channel header", "residual", "padding", "sample overflow",
-                                                "trailing bytes", "sample outside the bit depth", "not reached", "residual beyond 2^30"};
-            rc = decode_fail(LACX_E_RUNTIME, "[decode-error] block=" + std::to_string(b) + " " +
-                                                 (status[b] < 10 ? kWhat[status[b]] : "?"));
-            goto done;
+    DEC_TRY(hipGetDevice(&prev_device), "hipGetDevice");
+    if (prev_device == d->device) prev_device = -1;
+    else DEC_TRY(hipSetDevice(d->device), "hipSetDevice");
+    if (!d->ready) {
+        DEC_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate");
+        DEC_TRY(hipEventCreate(&d->e0), "hipEventCreate");
+        DEC_TRY(hipEventCreate(&d->e1), "hipEventCreate");
+        d->ready = true;
+    }
+    if (pay + kDecodeTailPad > d->pay_cap) {
+        if (d->d_pay) (void)hipFree(d->d_pay);
+        d->d_pay = nullptr;
+        d->pay_cap = 0;
+        const uint64_t cap = pay + pay / 8 + kDecodeTailPad;
+        DEC_TRY(hipMalloc((void**)&d->d_pay, cap), "hipMalloc(payload)");
+        d->pay_cap = cap;
+    }
+    if (nb > d->blocks_cap) {
+        if (d->d_offs) (void)hipFree(d->d_offs);
+        if (d->d_status) (void)hipFree(d->d_status);
+        if (d->d_ms) (void)hipFree(d->d_ms);
+        if (d->h_status) (void)hipHostFree(d->h_status);
+        if (d->h_offs) (void)hipHostFree(d->h_offs);
+        d->d_offs = nullptr;
+        d->d_status = nullptr;
+        d->d_ms = nullptr;
+        d->h_status = nullptr;
+        d->h_offs = nullptr;
+        d->blocks_cap = 0;
+        const uint32_t cap = nb + nb / 8 + 16;
+        DEC_TRY(hipMalloc((void**)&d->d_offs, 2 * ((size_t)cap + 1) * sizeof(unsigned long long)), "hipMalloc(offsets)");
+        DEC_TRY(hipMalloc((void**)&d->d_status, (size_t)cap * sizeof(uint32_t)), "hipMalloc(status)");
+        DEC_TRY(hipMalloc((void**)&d->d_ms, cap), "hipMalloc(flags)");
+        DEC_TRY(hipHostMalloc((void**)&d->h_status, (size_t)cap * sizeof(uint32_t), 0), "hipHostMalloc(status)");
+        DEC_TRY(hipHostMalloc((void**)&d->h_offs, 2 * ((size_t)cap + 1) * sizeof(unsigned long long), 0), "hipHostMalloc(offsets)");
+        d->blocks_cap = cap;
+    }
+    if (frames > d->pcm_cap || (info.channels == 2 && !d->d_right)) {
+        if (d->d_left) (void)hipFree(d->d_left);
+        if (d->d_right) (void)hipFree(d->d_right);
+        d->d_left = d->d_right = nullptr;
+        d->pcm_cap = 0;
+        DEC_TRY(hipMalloc((void**)&d->d_left, frames * sizeof(int32_t)), "hipMalloc(left)");
+        DEC_TRY(hipMalloc((void**)&d->d_right, frames * sizeof(int32_t)), "hipMalloc(right)");
+        d->pcm_cap = frames;
+    }
+    {
+        unsigned long long* byte_off = d->h_offs;
+        unsigned long long* frame_off = d->h_offs + nb + 1;
+        byte_off[0] = frame_off[0] = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            frame_off[b + 1] = frame_off[b] + be32(lac + 14 + entry * b);
+            byte_off[b + 1] = v2 ? 0 : byte_off[b] + be32(lac + 18 + 8ull * b);
         }
+        hipStream_t st = d->stream;
+        DEC_TRY(hipMemsetAsync(d->d_pay + pay, 0, kDecodeTailPad, st), "memset");  // the bit reader's look-ahead (decode.hip)
+        DEC_TRY(hipMemcpyAsync(d->d_offs, d->h_offs, noffs * sizeof(unsigned long long), hipMemcpyHostToDevice, st), "H2D offsets");
+        DEC_TRY(hipMemcpyAsync(d->d_pay, lac + head, pay, hipMemcpyHostToDevice, st), "H2D payload");
+        DEC_TRY(hipEventRecord(d->e0, st), "event record");
+        int32_t* dr = info.channels == 2 ? d->d_right : nullptr;
+        if (v2)
+            DEC_TRY(launch_decode_serial(nb, info.channels, info.stereo_mode, info.bit_depth, d->d_pay, (uint32_t)(8ull * pay), d->d_offs + nb + 1,
+                                         d->d_left, dr, d->d_status, d->d_ms, st), "decode launch");
+        else
+            DEC_TRY(launch_decode(nb, info.channels, info.stereo_mode, info.bit_depth, d->d_pay, d->d_offs, d->d_offs + nb + 1, d->d_left, dr,
+                                  d->d_status, d->d_ms, st), "decode launch");
+        DEC_TRY(hipEventRecord(d->e1, st), "event record");
+        DEC_TRY(hipMemcpyAsync(d->h_status, d->d_status, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "D2H status");
+        DEC_TRY(hipStreamSynchronize(st), "synchronize");
+        if (device_ms) (void)hipEventElapsedTime(device_ms, d->e0, d->e1);
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (d->h_status[b]) {  // the first failing block, like the reference's message (lac/decoder.cpp:24-32)
+                static const char* const kWhat[] = {"", "block header", "channel header", "residual", "padding", "sample overflow",
+                                                    "trailing bytes", "sample outside the bit depth", "not reached", "residual beyond 2^30"};
+                rc = decode_fail(LACX_E_RUNTIME, "[decode-error] block=" + std::to_string(b) + " " +
+                                                     (d->h_status[b] < 10 ? kWhat[d->h_status[b]] : "?"));
+                goto done;
+            }
+        }
+        // the two channels leave on two streams' worth of copy engine time: issue both, then wait
+        DEC_TRY(hipMemcpyAsync(left, d->d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H left");
+        if (info.channels == 2) DEC_TRY(hipMemcpyAsync(right, d->d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost, st), "D2H right");
+        DEC_TRY(hipStreamSynchronize(st), "synchronize");
     }
-    DEC_TRY(hipMemcpy(left, d_left, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H left");
-    if (info.channels == 2) DEC_TRY(hipMemcpy(right, d_right, frames * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H right");
 done:
 #undef DEC_TRY
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (d_pay) (void)hipFree(d_pay);
-    if (d_offs) (void)hipFree(d_offs);
-    if (d_left) (void)hipFree(d_left);
-    if (d_right) (void)hipFree(d_right);
-    if (d_status) (void)hipFree(d_status);
-    if (d_ms) (void)hipFree(d_ms);
     if (prev_device >= 0) (void)hipSetDevice(prev_device);
     return rc;
+}
+
+int lacx_decode(int device, const uint8_t* lac, uint64_t size, int32_t* left, int32_t* right, uint64_t frames,
+                float* device_ms) {
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev < 0 || dev >= kMaxDecodeDevices) {
+        if (lacx_device_count() <= 0) {  // (parse errors come first, as before)
+            lacx_stream_info info;
+            const int prc = lacx_stream_parse(lac, size, &info);
+            return prc ? prc : decode_fail(LACX_E_DEVICE, "no usable HIP device");
+        }
+        return decode_fail(LACX_E_DEVICE, "HIP device ordinal out of range");
+    }
+    SharedDecoder* sd = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_shared_mu);
+        if (!g_shared[dev]) {
+            g_shared[dev] = new SharedDecoder();
+            g_shared[dev]->dec.device = dev;
+        }
+        sd = g_shared[dev];
+    }
+    std::lock_guard<std::mutex> lock(sd->mu);
+    lacx_decoder* d = &sd->dec;
+    return lacx_decoder_decode(d, lac, size, left, right, frames, device_ms);
 }
 
 }  // extern "C"

@@ -190,6 +190,35 @@ uint64_t pinned_reservation(const lacx_encoder* e, uint64_t frames, int channels
     return frames * (uint64_t)channels * (e->cfg.bit_depth / 8u) * 5u / 4u + (uint64_t)nb * 64u + 4096u;
 }
 
+// Copy-engine drain of the payload: every range of stream indices the packer has reported complete (a pinned word per
+// range) is fetched from the device payload into the pinned result buffer with hipMemcpyAsync on a copy stream of its
+// own -- a copy engine, not CUs.  Called from wherever the calling thread waits: the launch phase of an encode whose
+// input is still uploading (chunk c's payload leaves while chunk c + 1's PCM arrives: PCIe is full duplex) and the wait
+// for the kernels in encode_device_end.
+void drain_pump(lacx_encoder* e) {
+    if (!e->pend.drained || e->pend.ranges == 0) return;
+    const volatile unsigned long long* flags = e->h_range;
+    while (e->pend.next_range < e->pend.ranges) {
+        const unsigned long long v = flags[e->pend.next_range];
+        if (v == 0) break;
+        const uint64_t end = v - 1u;
+        if (e->knobs.debug_drain)
+            std::fprintf(stderr, "[drain] range %u end %llu at %.3f ms\n", e->pend.next_range, (unsigned long long)end, ms_since(e->pend.t0));
+        if (end > e->pend.drained_to && end <= e->h_payload_cap) {
+            hipStream_t cs = (e->pend.next_range & 1u) && e->knobs.two_copy_streams ? e->copy_stream2 : e->copy_stream;
+            if (hipMemcpyAsync(e->h_payload + e->pend.drained_to, e->d_payload + e->pend.drained_to, end - e->pend.drained_to,
+                               hipMemcpyDeviceToHost, cs) != hipSuccess)
+                return;  // (the final copy in encode_device_end fetches what is missing)
+            e->pend.drained_to = end;
+            const double now = ms_since(e->pend.t0);
+            if (e->timing.drain_copies == 0) e->timing.drain_first_ms = now;
+            e->timing.drain_last_ms = now;
+            e->timing.drain_copies += 1;
+        }
+        ++e->pend.next_range;
+    }
+}
+
 // Part 1: enqueue everything (no host synchronisation).
 int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames,
                              hipStream_t user_stream, int layout, int layout_channels, const HostSrc* hs);
@@ -198,6 +227,7 @@ int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d
     const int rc = encode_device_begin_impl(e, d_left, d_right, frames, user_stream, layout, layout_channels, hs);
     // A failure half-way leaves kernels queued that write to the workspace, the slots and the pinned result buffer: they
     // must have drained before the next call clears, frees or regrows any of those.
+    if (rc != LACX_OK && e->uploader) e->uploader->wait();  // (it reads the caller's buffer and writes this encoder's)
     if (rc != LACX_OK && e->device_ready) (void)hipDeviceSynchronize();
     return rc;
 }
@@ -268,7 +298,14 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     }
     reset_device_timing(e);
     e->timing.emit_ms = 0;
+    e->timing.drain_copies = 0;
+    e->timing.drain_first_ms = e->timing.drain_last_ms = e->timing.poll_gap_max_ms = e->timing.kernels_done_ms = 0;
     const auto t0 = clk::now();
+    e->pend.t0 = t0;
+    e->pend.drained = false;  // (set once the packer is launched: drain_pump looks at it)
+    e->pend.ranges = 0;
+    e->pend.next_range = 0;
+    e->pend.drained_to = 0;
     for (int c = 0; c < kMaxChunks; ++c) e->h_totals[c] = 0;  // (the last chunk's total doubles as the "all kernels done" word)
     hipStream_t st[kStreams];
     for (int i = 0; i < kStreams; ++i) st[i] = e->stream[i];
@@ -305,10 +342,46 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         const bool last_both_ways = channels == 2 && e->cfg.stereo_mode == 2 && last_frames <= (uint64_t)kFullCompareLimit;
         fuse_items = (nb - (last_both_ways ? 1u : 0u)) * (uint32_t)channels;
     }
+    if (hs) {
+        if (!e->uploader) {
+            e->uploader.reset(new Uploader());
+            HIP_TRY(e, hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking), "hipStreamCreate");
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HIP_TRY(e, hipStreamCreateWithPriority(&e->front_stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
+            for (auto& ev : e->up_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        }
+        for (auto& d : e->up_done) d.store(0, std::memory_order_relaxed);
+        e->up_ms = 0;
+        const HostSrc src = *hs;
+        const std::vector<Chunk> plan = chunks;
+        const int dev = e->device;
+        uint8_t* dst0 = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_left));
+        uint8_t* dst1 = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_right));
+        e->uploader->post([e, src, plan, dev, dst0, dst1, frames] {
+            (void)hipSetDevice(dev);
+            const auto tu0 = clk::now();
+            bool ok = true;
+            for (size_t c = 0; c < plan.size(); ++c) {
+                const uint64_t f0 = (uint64_t)plan[c].first * kMaxBlock;
+                const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(plan[c].first + plan[c].count) * kMaxBlock);
+                const uint64_t o = f0 * src.frame_bytes, nbytes = (f1 - f0) * src.frame_bytes;
+                if (ok) ok = hipMemcpyAsync(dst0 + o, src.p0 + o, nbytes, hipMemcpyHostToDevice, e->up_stream) == hipSuccess;
+                if (ok && src.p1) ok = hipMemcpyAsync(dst1 + o, src.p1 + o, nbytes, hipMemcpyHostToDevice, e->up_stream) == hipSuccess;
+                if (ok) ok = hipEventRecord(e->up_ev[c], e->up_stream) == hipSuccess;
+                e->up_done[c].store(ok ? 1 : -1, std::memory_order_release);
+            }
+            e->up_ms = ms_since(tu0);
+        });
+    }
+    // Upload pipeline with the front kernels on their own (highest priority) stream: the chunks' whole-block kernels then
+    // run on the encoder's lower-priority streams only (stream 0 shares the top priority with the front stream).
+    const bool front_split = hs && kn.front_stream_split && chunks.size() > 1 && !user_stream;
+    auto chunk_stream = [&](size_t c) { return front_split ? st[1 + c % (kStreams - 1)] : st[c % kStreams]; };
     for (size_t c = 0; c < chunks.size(); ++c) {
         const Chunk& ck = chunks[c];
-        hipStream_t s = st[c % kStreams];
-        if (c % kStreams != 0) HIP_TRY(e, hipStreamWaitEvent(s, e->prologue, 0), "stream wait");
+        hipStream_t s = chunk_stream(c);
+        if (s != st[0]) HIP_TRY(e, hipStreamWaitEvent(s, e->prologue, 0), "stream wait");
         const ChunkCtx cx = chunk_ctx(e, d_left, d_right, frames, layout, channels, ck, c);
         const AnalyzeParams& prm = cx.prm;
         const int32_t *cl = cx.left, *cr = cx.right;
@@ -322,17 +395,25 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
             fa.size_rec = e->ws.size_rec;
             fa.ready_rec = e->ws.ready_rec;
         }
-        if (hs) {  // this chunk's PCM: host -> device, on the chunk's stream, right in front of its kernels
-            const auto th0 = clk::now();
-            const uint64_t f0 = (uint64_t)ck.first * kMaxBlock;
-            const uint64_t f1 = std::min<uint64_t>(frames, (uint64_t)(ck.first + ck.count) * kMaxBlock);
-            const uint64_t o = f0 * hs->frame_bytes, nbytes = (f1 - f0) * hs->frame_bytes;
-            HIP_TRY(e, hipMemcpyAsync(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_left)) + o, hs->p0 + o, nbytes,
-                                      hipMemcpyHostToDevice, s), "H2D pcm");
-            if (hs->p1)
-                HIP_TRY(e, hipMemcpyAsync(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(d_right)) + o, hs->p1 + o, nbytes,
-                                          hipMemcpyHostToDevice, s), "H2D pcm");
-            e->timing.h2d_ms += ms_since(th0);
+        if (hs) {
+            // this chunk's PCM is being copied by the uploader thread: wait (on the host) until its copy has been issued and
+            // its event recorded, then make the chunk's stream wait for that event
+            const auto tw0 = clk::now();
+            int st_up = 0;
+            while ((st_up = e->up_done[c].load(std::memory_order_acquire)) == 0) {
+                drain_pump(e);  // earlier chunks' payload leaves while this chunk's PCM arrives
+                __builtin_ia32_pause();
+                if (ms_since(tw0) > 20000.0) break;
+            }
+            if (st_up != 1) {
+                e->uploader->wait();
+                return fail(e, LACX_E_DEVICE, "host to device copy of the PCM failed");
+            }
+            HIP_TRY(e, hipStreamWaitEvent(s, e->up_ev[c], 0), "stream wait");
+            if (front_split) {
+                HIP_TRY(e, hipStreamWaitEvent(e->front_stream, e->up_ev[c], 0), "stream wait");
+                if (c == 0) HIP_TRY(e, hipStreamWaitEvent(e->front_stream, e->prologue, 0), "stream wait");
+            }
         }
         // Fused emit: the packer walks the stream indices in order, so the whole-block kernels of the chunks run in that
         // order too (chunk c's waits for chunk c-1's: ev[c-1][3] is recorded behind it); what comes before them --
@@ -346,7 +427,9 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         // Levinson / probe kernels are meant to run beside this chunk's analysis, which persistent workgroups would not let in
         DeviceWorkspace wl = w;
         if (chunks.size() > 1 || !kn.persistent) wl.work_ctr = nullptr;
-        HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr, kn.tune), "kernel launch");
+        LaunchTuning tune = kn.tune;
+        if (front_split) tune.front_stream = e->front_stream;
+        HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr, tune), "kernel launch");
         if (c == 0 && fuse_items && kn.packer) {
             // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first
             // chunk's ingest / Levinson / probe kernels are done (ev[0][2] is recorded right in front of the whole-block
@@ -370,6 +453,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
                 rp.fuse_total = fuse_items;
                 rp.fence_mode = kn.drain_fence;
                 e->pend.ranges = ranges;
+                e->pend.drained = true;
             }
             HIP_TRY(e, launch_stream_out(bind(shard), e->ws, emit_dst, e->ws.err_flag + kMaxChunks, e->pack_stream, rp, kn.tune), "packer launch");
             HIP_TRY(e, hipEventRecord(e->pack_done, e->pack_stream), "event record");
@@ -380,7 +464,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     // chunks, so none of this may be enqueued before the last chunk's analysis kernels.
     for (size_t c = 0; c < chunks.size(); ++c) {
         const Chunk& ck = chunks[c];
-        hipStream_t s = st[c % kStreams];
+        hipStream_t s = chunk_stream(c);
         const ChunkCtx cx = chunk_ctx(e, d_left, d_right, frames, layout, channels, ck, c);
         const AnalyzeParams& prm = cx.prm;
         const int32_t *cl = cx.left, *cr = cx.right;
@@ -431,6 +515,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     e->pend.drained = drained;  // (the result is fetched from the device payload even when no range was ever reported)
     if (!(drained && fused && fuse_items != 0)) e->pend.ranges = 0;
     for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
+    e->pend.front_split = front_split;
     e->pend.t0 = t0;
     e->pend.d_left = d_left;
     e->pend.d_right = d_right;
@@ -483,6 +568,11 @@ int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size) {
 int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     if (!e->pend.active) return fail(e, LACX_E_RUNTIME, "no encode in flight on this encoder");
     e->pend.active = false;
+    if (e->uploader) {  // (long finished: every chunk's kernels were enqueued behind its copy)
+        e->uploader->wait();
+        if (e->up_ms > 0) e->timing.h2d_ms = e->up_ms;
+        e->up_ms = 0;
+    }
     const std::vector<Chunk>& chunks = e->pend.chunks;
     const uint32_t nb = e->pend.nb;
     const int channels = e->pend.channels;
@@ -494,33 +584,8 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     size_t copies = 0;
     // Copy-engine drain: while the kernels run, every range of stream indices the packer reports complete is fetched
     // from the device payload into the pinned result buffer (hipMemcpyAsync on its own stream: a copy engine, not CUs).
-    uint64_t drained_to = 0;
-    e->timing.drain_copies = 0;
-    e->timing.drain_first_ms = e->timing.drain_last_ms = e->timing.poll_gap_max_ms = e->timing.kernels_done_ms = 0;
-    const bool dbg_drain = e->knobs.debug_drain;
-    const bool two_streams = e->knobs.two_copy_streams;
     if (e->pend.drained) {
-        uint32_t next = 0;
-        const volatile unsigned long long* flags = e->h_range;
-        auto pump = [&]() {
-            while (next < e->pend.ranges) {
-                const unsigned long long v = flags[next];
-                if (v == 0) break;
-                const uint64_t end = v - 1u;
-                if (dbg_drain) std::fprintf(stderr, "[drain] range %u end %llu at %.3f ms\n", next, (unsigned long long)end, ms_since(t0));
-                if (end > drained_to && end <= e->h_payload_cap) {
-                    if (hipMemcpyAsync(e->h_payload + drained_to, e->d_payload + drained_to, end - drained_to, hipMemcpyDeviceToHost,
-                                       (next & 1u) && two_streams ? e->copy_stream2 : e->copy_stream) != hipSuccess)
-                        return;  // (the final copy below fetches what is missing)
-                    drained_to = end;
-                    const double now = ms_since(t0);
-                    if (e->timing.drain_copies == 0) e->timing.drain_first_ms = now;
-                    e->timing.drain_last_ms = now;
-                    e->timing.drain_copies += 1;
-                }
-                ++next;
-            }
-        };
+        auto pump = [&]() { drain_pump(e); };
         // (no runtime call in the loop but the copies: the gather kernel -- the last one of the call -- stores the
         // cumulative byte count of the last chunk, non-zero, into pinned memory that was zeroed before the launch)
         const volatile unsigned long long* finished = &e->h_totals[chunks.size() - 1];
@@ -546,10 +611,11 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
             __builtin_ia32_pause();
         }
         e->timing.kernels_done_ms = ms_since(t0);
-        if (dbg_drain) std::fprintf(stderr, "[drain] kernels done at %.3f ms, copy stream %s\n", ms_since(t0),
-                                    hipStreamQuery(e->copy_stream) == hipSuccess ? "idle" : "busy");
+        if (e->knobs.debug_drain) std::fprintf(stderr, "[drain] kernels done at %.3f ms, copy stream %s\n", ms_since(t0),
+                                               hipStreamQuery(e->copy_stream) == hipSuccess ? "idle" : "busy");
         pump();
     }
+    uint64_t drained_to = e->pend.drained_to;
     for (size_t c = 0; c < chunks.size(); ++c) {
         const hipError_t he = hipEventSynchronize(e->done[c]);
         if (he != hipSuccess) {
@@ -574,7 +640,7 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
             break;
         }
         if (staged) {
-            hipStream_t s = st[c % kStreams];
+            hipStream_t s = e->pend.front_split ? st[1 + c % (kStreams - 1)] : st[c % kStreams];
             const hipError_t ce = hipMemcpyAsync(e->h_payload + off, e->d_payload + off, end - off, hipMemcpyDeviceToHost, s);
             if (ce != hipSuccess || hipEventRecord(e->done[c], s) != hipSuccess) {
                 status = hip_fail(e, ce, "D2H payload");

@@ -5,7 +5,11 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,8 +68,62 @@ struct Knobs {
     uint32_t pipe_chunks = 0;      // LACX_PIPE_CHUNKS
     std::string pipe_split;        // LACX_PIPE_SPLIT
     uint32_t drain_fence = 0;      // LACX_DRAIN_FENCE
+    bool front_stream_split = false; // LACX_FRONT_STREAM: upload pipeline with the front kernels on a high-priority stream (experiment)
     uint32_t fanout_exchange = 0;  // LACX_FANOUT_EXCHANGE: 0 auto (RCCL where the devices are distinct), 1 host, 2 rccl
     LaunchTuning tune;             // LACX_PERSISTENT_GRID, LACX_PACK_NAP, LACX_PACK_GRID
+};
+
+// One persistent host thread per encoder that performs the host-to-device copies of an encode whose input starts in host
+// memory.  hipMemcpyAsync from pageable memory returns only when the copy is (all but) done, so issued from the calling
+// thread every chunk's upload stands between that thread and the next chunk's kernel launches; issued from here, the
+// calling thread enqueues chunk c's kernels the moment chunk c's bytes are on their way, while chunk c + 1 is uploading.
+class Uploader {
+public:
+    Uploader() : th_([this] { loop(); }) {}
+    ~Uploader() {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            job_ = std::move(job);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return !busy_; });
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return busy_ || quit_; });
+                if (quit_) return;
+                job = std::move(job_);
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> lock(mu_);
+                busy_ = false;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false;
+    std::thread th_;
 };
 
 struct Fanout;  // api_fanout.cpp: the lanes of an encoder that spreads a stream over several devices
@@ -101,6 +159,9 @@ struct lacx_encoder {
         bool fused = false;
         bool drained = false;     // packer -> d_payload, copy engine -> h_payload (see h_range)
         uint32_t ranges = 0;
+        bool front_split = false;  // upload pipeline: chunk c ran on stream 1 + c % 3
+        uint32_t next_range = 0;  // copy-engine drain: first range not yet looked at, bytes already on their way
+        uint64_t drained_to = 0;
         hipStream_t st[4] = {};
         clk::time_point t0;
         // inputs of the call, kept for the re-emit after a too-small result reservation
@@ -147,6 +208,13 @@ struct lacx_encoder {
     uint32_t* d_range_cnt = nullptr;        // device, inside zero_region
     unsigned long long* d_range_end = nullptr;
     std::unique_ptr<EmitPool> pool;
+    // host-resident input: the uploader thread, its stream, one event per pipeline chunk, and the hand-over words
+    std::unique_ptr<Uploader> uploader;
+    hipStream_t up_stream = nullptr;
+    hipStream_t front_stream = nullptr;  // upload pipeline: every chunk's front kernels, above the chunk streams in priority
+    hipEvent_t up_ev[kMaxChunks] = {};
+    std::atomic<int> up_done[kMaxChunks] = {};  // 1: the chunk's copy has been issued and its event recorded; -1: failed
+    double up_ms = 0;                           // host time the uploader spent in the copies of the call
     std::string err;
     int bad_channel = -1;    // last sample-range error: 0 left / 1 right, and the sample's index in the call's input
     uint64_t bad_index = 0;  // (the fan-out rebuilds the reference's message with the stream-wide index)
@@ -194,6 +262,7 @@ uint64_t pinned_reservation(const lacx_encoder* e, uint64_t frames, int channels
 int encode_device_begin(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, hipStream_t user_stream, int layout = 0, int layout_channels = 0, const HostSrc* hs = nullptr);
 int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, hipStream_t user_stream, int layout, int layout_channels, const HostSrc* hs);
 int reemit_into_regrown_buffer(lacx_encoder* e, uint64_t* payload_size);
+void drain_pump(lacx_encoder* e);
 int encode_device_end(lacx_encoder* e, uint64_t* payload_size);
 int encode_pipelined_device(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, hipStream_t user_stream, uint64_t* payload_size, int layout = 0, int layout_channels = 0, const HostSrc* hs = nullptr);
 int fetch_pcm_if_needed(lacx_encoder* e, const int32_t* d_left, const int32_t* d_right, uint64_t frames, const int32_t*& h_left, const int32_t*& h_right, std::vector<int32_t>& tl, std::vector<int32_t>& tr);

@@ -868,6 +868,8 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     const BatchRef& br = ls.br;
     const uint32_t nb = br.total_blocks;
     if (nb == 0) return hipSuccess;
+    hipStream_t full_stream = stream;  // the whole-block kernel and everything behind it
+    if (tune.front_stream && ev) stream = tune.front_stream;  // the front kernels (needs ev[2] to order the two)
     if (ev) (void)hipEventRecord(ev[0], stream);
     e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
     if (e != hipSuccess) return e;
@@ -896,6 +898,11 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
                            ws.need_full, ws.plans);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
+    if (full_stream != stream) {
+        const hipError_t we = hipStreamWaitEvent(full_stream, ev[2], 0);
+        if (we != hipSuccess) return we;
+        stream = full_stream;
+    }
     if (wait_before_full) {
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_full, 0);
         if (we != hipSuccess) return we;

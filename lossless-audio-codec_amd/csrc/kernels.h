@@ -51,6 +51,11 @@ struct LaunchTuning {
     int pack_nap = 0;              // the streaming packer's polling pause (0 = default)
     int pack_grid = 0;             // the streaming packer's workgroups (0 = default)
     bool no_pairs = false;         // persistent analysis: hand every slot out singly (LACX_NO_PAIRS; A/B of the pair units)
+    // Front kernels (ingest, stereo, Levinson, probes, decision) on a stream of their own: `stream` of launch_analysis then
+    // carries only the whole-block kernel and what follows, ordered behind the front by an event.  Used by the upload
+    // pipeline with a high-priority front stream: the next chunk's front kernels -- short, latency-bound -- then take the
+    // CUs that the current chunk's whole-block workgroups free one by one instead of waiting for the end of that kernel.
+    hipStream_t front_stream = nullptr;
 };
 
 // Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while

@@ -104,6 +104,7 @@ EXPORTS = (
     "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error", "lacx_encode_batch_device",
     "lacx_encoder_create_multi", "lacx_encoder_lanes", "lacx_fanout_range", "lacx_encode_fanout_resident",
     "lacx_get_fanout_stats", "lacx_get_lane_timing", "lacx_fanout_exchange_note",
+    "lacx_decoder_create", "lacx_decoder_destroy", "lacx_decoder_decode",
 )
 
 
@@ -598,6 +599,55 @@ def decode(lac: bytes, device: int = -1):
     if rc != OK:
         raise RuntimeError(lib().lacx_decode_last_error().decode(errors="replace"))
     return left, right, info, float(ms.value)
+
+
+class Decoder:
+    """Mirror of LAC::Decoder (ref src/codec/lac/decoder.hpp:10-24) over a decoder handle (lacx_decoder_create): the device
+    buffers live from call to call, and so do the output arrays when `reuse_output` is set (a fresh numpy array of a few
+    hundred MB costs more in first-touch page faults than the decode itself)."""
+
+    def __init__(self, device: int = -1, reuse_output: bool = False):
+        h = C.c_void_p()
+        if lib().lacx_decoder_create(C.c_int(device), C.byref(h)) != OK:
+            raise RuntimeError("lacx_decoder_create failed")
+        self._h = h
+        self._reuse = reuse_output
+        self._left = self._right = None
+
+    def close(self):
+        if self._h is not None:
+            lib().lacx_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, lac: bytes):
+        """(left, right or None, StreamInfo, kernel milliseconds); RuntimeError("[decode-error] ...") like the reference."""
+        info = StreamInfo()
+        buf = np.frombuffer(lac, dtype=np.uint8)
+        bp = buf.ctypes.data_as(C.POINTER(C.c_uint8))
+        if lib().lacx_stream_parse(bp, C.c_uint64(buf.size), C.byref(info)) != OK:
+            raise RuntimeError(lib().lacx_decode_last_error().decode(errors="replace"))
+        if self._reuse and self._left is not None and self._left.size == info.frames:
+            left, right = self._left, (self._right if info.channels == 2 else None)
+        else:
+            left = np.empty(info.frames, dtype=np.int32)
+            right = np.empty(info.frames, dtype=np.int32) if info.channels == 2 else None
+        if right is None and info.channels == 2:
+            right = np.empty(info.frames, dtype=np.int32)
+        if self._reuse:
+            self._left, self._right = left, right
+        ms = C.c_float()
+        rc = lib().lacx_decoder_decode(self._h, bp, C.c_uint64(buf.size), left.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       right.ctypes.data_as(C.POINTER(C.c_int32)) if right is not None else None,
+                                       C.c_uint64(info.frames), C.byref(ms))
+        if rc != OK:
+            raise RuntimeError(lib().lacx_decode_last_error().decode(errors="replace"))
+        return left, right, info, float(ms.value)
 
 
 def assemble(sample_rate: int, bit_depth: int, stereo_mode: int, channels: int, shards) -> bytes:

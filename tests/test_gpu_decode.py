@@ -273,3 +273,27 @@ def test_legacy_version_2_container(gpu):
             gpu.lacx.decode(v2 + b"\0")  # trailing frame payload
         with pytest.raises(RuntimeError, match="decode-error"):
             gpu.lacx.decode(v2[:-1])
+
+
+def test_decoder_handle_reuses_its_buffers(gpu, oracle):
+    """lacx_decoder_create / lacx_decoder_decode: one handle through streams of different sizes, formats and channel counts
+    (buffers grow, never shrink), a malformed stream in between, and the handle-less lacx_decode beside it."""
+    dec = gpu.lacx.Decoder(device=0, reuse_output=True)
+    for frames, ch, bd, sr, sm, kind in ((16384 * 3 + 9, 2, 16, 48000, 2, "mixed"), (16384 * 9 + 100, 2, 24, 96000, 2, "music"),
+                                          (5000, 1, 16, 44100, 0, "noise"), (16384 * 9 + 100, 2, 24, 96000, 0, "sparse"),
+                                          (16384 * 20, 1, 24, 192000, 0, "music")):
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=90, kind=kind)
+        lac = oracle.encode(left, right, sr, bd, sm, threads=8)
+        for _ in range(2):
+            l, r, info, ms = dec.decode(lac)
+            assert np.array_equal(l, left) and (r is None) == (ch == 1) and (ch == 1 or np.array_equal(r, right))
+            assert (info.frames, info.channels, info.bit_depth) == (frames, ch, bd) and ms > 0
+        bad = bytearray(lac)
+        bad[len(bad) // 2] ^= 0x55
+        try:
+            dec.decode(bytes(bad))
+        except RuntimeError as ex:
+            assert "[decode-error]" in str(ex)
+        l2, r2, _, _ = gpu.lacx.decode(lac)
+        assert np.array_equal(l2, left)
+    dec.close()
