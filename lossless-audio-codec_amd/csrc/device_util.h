@@ -231,12 +231,18 @@ __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t*
 // wave on the DPP network and lane 63 adds them to the block's (ksum[k]; ksum256[k], k <= 12, for the first 256
 // samples: the lanes 0 .. W256-1 of wave 0, an intermediate of the same scan).  About 260 vector instructions per
 // wave and candidate against ninety ballot -> scalar round trips (measured: 25 000 -> 10 000 cycles per candidate).
+// kmask (wave-uniform): the parameters k whose block sum the scoring can need (static_k_candidates); the others are
+// skipped -- except in wave 0, whose first DPP row also feeds the sums over the first 256 samples (k <= 12, all needed by
+// the initial-k estimate): there the row sum is still formed and the rest of the reduction left out.
 template <class G>
-__device__ __forceinline__ void ksums_wave(const Thread<G>& th, uint32_t* ksum, uint32_t* ksum256, int tid) {
+__device__ __forceinline__ void ksums_wave(const Thread<G>& th, uint32_t* ksum, uint32_t* ksum256, int tid, uint32_t kmask = 0xFFFFu) {
     const int lane = tid & 63, wave = tid >> 6;
     static_assert(G::W256 == 16 || G::W256 == 64, "the first 256 samples are one DPP row or the whole wave");
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        const bool wanted = ((kmask >> k) & 1u) != 0u;                 // (uniform)
+        const bool head256 = wave == 0 && k <= 12;                     // (uniform)
+        if (!wanted && !head256) continue;
         uint32_t v = 0;
 #pragma unroll
         for (int l = 0; l < G::LV; ++l) v += (th.cs[l] >> k) << l;
@@ -245,14 +251,31 @@ __device__ __forceinline__ void ksums_wave(const Thread<G>& th, uint32_t* ksum, 
         v += dpp_mov<kDppRowShr4, 0xF>(0u, v);
         v += dpp_mov<kDppRowShr8, 0xF>(0u, v);
         const uint32_t row = v;  // lane 15: the sum over lanes 0..15
-        v += dpp_mov<kDppRowBcast15, 0xA>(0u, v);
-        v += dpp_mov<kDppRowBcast31, 0xC>(0u, v);
-        if (lane == 63) {
-            atomicAdd(&ksum[k], v);
-            if (G::W256 == 64 && wave == 0 && k <= 12) atomicAdd(&ksum256[k], v);
+        if (wanted || G::W256 == 64) {
+            v += dpp_mov<kDppRowBcast15, 0xA>(0u, v);
+            v += dpp_mov<kDppRowBcast31, 0xC>(0u, v);
+            if (lane == 63) {
+                if (wanted) atomicAdd(&ksum[k], v);
+                if (G::W256 == 64 && wave == 0 && k <= 12) atomicAdd(&ksum256[k], v);
+            }
         }
         if (G::W256 == 16 && wave == 0 && lane == 15 && k <= 12) atomicAdd(&ksum256[k], row);
     }
+}
+
+// The static parameters k that can still be the argmin of A_k + n (1 + k), A_k = sum_j (u_j >> k), given only the block's
+// S = sum_j u_j and n (ref block/encoder.cpp:160-180 evaluates all sixteen): floor-of-sum bounds each A_k,
+//   (S - n (2^k - 1)) / 2^k <= A_k <= S >> k,
+// so a k whose lower cost bound exceeds the smallest upper bound over all k can neither be the minimum nor tie with it.
+// Typically four of the sixteen remain (k* - 1 .. k* + 2 around S / n).  Returns the mask of the k to evaluate.
+__device__ __forceinline__ uint32_t static_k_candidates(uint32_t S, uint32_t n, int lane) {
+    const uint32_t k = (uint32_t)lane & 15u;
+    const uint64_t fixed = (uint64_t)n * (1u + k);
+    const uint64_t upper = (uint64_t)(S >> k) + fixed;
+    const uint64_t slack = (uint64_t)n * ((1u << k) - 1u);
+    const uint64_t lower = ((uint64_t)S > slack ? (((uint64_t)S - slack + ((1u << k) - 1u)) >> k) : 0ull) + fixed;
+    const uint64_t umin = wave_last_u64(wave_scan_min_u64(lane < 16 ? upper : ~0ull));
+    return (uint32_t)__ballot(lane < 16 && lower <= umin) & 0xFFFFu;
 }
 
 // Exclusive scan of an LDS array by one wave (row of 64 at a time, running carry).

@@ -34,6 +34,9 @@ __device__ __forceinline__ void scan_nx_part2(M& sh, int tid, int32_t inc, const
 }
 
 
+#ifndef LACX_WALK2_SINK
+#define LACX_WALK2_SINK 0  // 1: the register-accumulator form (A/B)
+#endif
 // Walk 2 for the common shape of a channel block (device only): the whole bitstream fits ONE output tile (every 16-bit
 // block, most 24-bit ones), the lane's chunk is complete and lies inside one partition, and that partition is coded with
 // plain Rice tokens (mode 0 adaptive / 3 static) -- all of it for every lane of the wave, so the choice is one scalar
@@ -46,6 +49,7 @@ template <class G, class M>
 __device__ __forceinline__ void emit_walk2_rice(const Thread<G>& th, M& sh, uint32_t* __restrict__ words, uint32_t pos,
                                                 bool is_static, uint32_t k0) {
     const int t = th.tid;
+#if LACX_WALK2_SINK
     uint64_t acc = 0;              // pending bits, left-aligned
     uint32_t fill = pos & 31u;     // number of pending bits (< 32 between samples)
     uint32_t word = pos >> 5;
@@ -66,6 +70,20 @@ __device__ __forceinline__ void emit_walk2_rice(const Thread<G>& th, M& sh, uint
             shared = false;
         }
     };
+#else
+    // Every token goes straight to its place: OR-ed into the one or two words it covers (the tile is zeroed; tokens of
+    // different threads meet in a word at most at the ends of their ranges, and a ds_or is as cheap as a store).  No
+    // carried accumulator, no data-dependent flush: the only chain from sample to sample is the bit position.
+    auto put = [&](uint32_t value, uint32_t n) {  // n in 1..32, value < 2^n, MSB first
+        const uint32_t sh_ = pos & 31u;
+        const uint64_t v64 = (uint64_t)value << (64u - sh_ - n);
+        const uint32_t hi = (uint32_t)(v64 >> 32), lo = (uint32_t)v64;
+        uint32_t* w = &words[pos >> 5];
+        if (hi) atomicOr(w, hi);
+        if (lo) atomicOr(w + 1, lo);
+        pos += n;
+    };
+#endif
 #pragma unroll 4
     for (int i = 0; i < G::CH; ++i) {
         const uint32_t u = sh.u[i * G::T + t] & 0x3FFFFFFFu;
@@ -83,7 +101,9 @@ __device__ __forceinline__ void emit_walk2_rice(const Thread<G>& th, M& sh, uint
             put(rem, k + 1u);
         }
     }
+#if LACX_WALK2_SINK
     if (fill) atomicOr(&words[word], (uint32_t)(acc >> 32));  // the last, partial word is shared with the next thread
+#endif
 }
 
 // Emit of one channel block from the residual in sh.u (plain zigzag values, block scans of tabP / tabNZ / tabNX done,

@@ -134,10 +134,10 @@ __device__ __forceinline__ void publish_pending(const FuseArgs& fa, PendingSlot&
 template <class G>
 __device__ __forceinline__ void score_candidate_wave(Smem<G>& sh, int cand, uint32_t n, int zero_run, uint32_t k0,
                                                      const uint32_t* planeTot, const unsigned long long* acc, int lane,
-                                                     bool ksums) {
+                                                     bool ksums, uint32_t kmask) {
     uint64_t key = ~0ull;
-    if (ksums) {  // planeTot[k] = sum_j (u_j >> k) already (ksums_wave)
-        if (lane < 16) key = (((uint64_t)planeTot[lane] + (uint64_t)n * (uint64_t)(1 + lane)) << 4) | (uint64_t)lane;
+    if (ksums) {  // planeTot[k] = sum_j (u_j >> k) already (ksums_wave), for the k of kmask (the others cannot win)
+        if (lane < 16 && ((kmask >> lane) & 1u)) key = (((uint64_t)planeTot[lane] + (uint64_t)n * (uint64_t)(1 + lane)) << 4) | (uint64_t)lane;
     } else {
         const int b = 29 - lane;
         const uint64_t w = (lane < 30) ? ((uint64_t)planeTot[b] << b) : 0ull;
@@ -310,6 +310,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     int pending = -1;        // candidate whose totals still have to be scored
     uint32_t pending_k0 = 0;
     bool pending_ksums = false;  // its totals are k-sums (32-bit blocks), not plane counts
+    uint32_t pending_kmask = 0xFFFFu;  // ... for these k only
     uint32_t tried = 0;      // candidates already evaluated (uniform)
     int parity = 0;
     for (;;) {
@@ -320,7 +321,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         if (tid < 64) {  // wave 0
             if (pending >= 0) {
                 // previous candidate's totals sit in the other buffers: score it, then clear them
-                score_candidate_wave(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1], tid, pending_ksums);
+                score_candidate_wave(sh, pending, n, prm.zero_run, pending_k0, sh.planeTot[parity ^ 1], sh.acc[parity ^ 1], tid, pending_ksums, pending_kmask);
                 if (tid < 32) sh.planeTot[parity ^ 1][tid] = sh.planeTot256[parity ^ 1][tid] = 0;
                 if (tid < 4) sh.acc[parity ^ 1][tid] = 0;
             }
@@ -357,8 +358,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         const uint64_t total_u = scan_pz_part2(sh, tid, sr);
         const bool narrow = total_u < kNarrowLimit;  // all prefix sums fit 32 bits (uniform)
         const bool ksums = narrow && !LACX_HOOK(prm, 262144u);
+        // (the k whose static cost can still be the smallest follow from the block's sum alone: about four of sixteen)
+        const uint32_t kmask = (ksums && !LACX_HOOK(prm, 1048576u)) ? static_k_candidates((uint32_t)total_u, n, tid & 63) : 0xFFFFu;
         if (!LACX_HOOK(prm, 1u)) {
-            if (ksums) ksums_wave(th, pt, pt256, tid); else plane_totals_wave(th, pt, pt256, tid);
+            if (ksums) ksums_wave(th, pt, pt256, tid, kmask); else plane_totals_wave(th, pt, pt256, tid);
         }
         // the first 256 samples all belong to wave 0: its own totals are complete once its atomics are (same wave,
         // program order), so it can derive the initial k at once; every other thread reads it after B3
@@ -451,6 +454,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         pending = cand;
         pending_k0 = k0;
         pending_ksums = ksums;
+        pending_kmask = kmask;
         parity ^= 1;
     }
 
