@@ -187,6 +187,18 @@ __device__ __forceinline__ uint32_t initial_k_wave(const uint32_t* planes256, ui
 // ---------------------------------------------------------------------------------------------
 // k_analyze
 // ---------------------------------------------------------------------------------------------
+// Barrier between the phases of a slot.  A probe slot is one wave: its LDS accesses execute in order, so all it needs is
+// that they have completed (and that the compiler keeps its order) -- no s_barrier, which lets the twelve probe slots of a
+// block share a workgroup without sharing trip counts.
+template <class G>
+__device__ __forceinline__ void slot_sync() {
+    if constexpr (G::T == 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        __syncthreads();
+    }
+}
+
 // The analysis of one slot (everything after the slot has been picked).
 template <class G>
 __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const AnalyzeParams& prm, uint32_t n_in,
@@ -219,7 +231,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         sh.tabUZ[G::T] = sh.tabUZ[G::T + 1] = 0;  // "not a zero" past the slot (phase_b_quick)
     }
     if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous slot's stores (long drained; free when there are none)
-    __syncthreads();
+    slot_sync<G>();
     if (pend) publish_pending(fuse, *pend, tid);
     STAMP(0);
 
@@ -292,7 +304,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     run_pass1(true);
     STAMP(2);
 #endif
-    __syncthreads();
+    slot_sync<G>();
     if (tid <= 10) {
         // one lane per candidate: its bound as a sortable key (bound * 16 + index), all ones when it is not available
         const bool avail = !((tid >= 6 && (sh.lpc.used[tid >= 6 ? tid - 6 : 0] == 0 || LACX_HOOK(prm, 16u))) ||
@@ -337,7 +349,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             }
         }
         STAMP(1);
-        __syncthreads();  // Bsel: the previous candidate is scored, the next one chosen
+        slot_sync<G>();  // Bsel: the previous candidate is scored, the next one chosen
         STAMP(4);
         const int cand = sh.next_cand;
         if (cand < 0) break;  // uniform
@@ -354,7 +366,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
         STAMP(3);
-        __syncthreads();  // B1b: the wave totals of the scan
+        slot_sync<G>();  // B1b: the wave totals of the scan
         const uint64_t total_u = scan_pz_part2(sh, tid, sr);
         const bool narrow = total_u < kNarrowLimit;  // all prefix sums fit 32 bits (uniform)
         const bool ksums = narrow && !LACX_HOOK(prm, 262144u);
@@ -380,7 +392,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         }
         if (__ballot(th.has4 != 0u) != 0ull && (tid & 63) == 0) sh.has4[parity] = 1u;  // read after B3
         STAMP(8);
-        __syncthreads();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own), prefixes in tabP
+        slot_sync<G>();  // B3: every chunk's flag counts are in tabF (phase B sums the six before its own), prefixes in tabP
         STAMP(10);
         const uint32_t k0 = sh.cur_k0;
         // (nothing derived from the thread index is carried from outside the candidate loop into phase B: the compiler
@@ -419,7 +431,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                     }
                 }
                 STAMP(11);
-                __syncthreads();  // Bq: the queue is complete
+                slot_sync<G>();  // Bq: the queue is complete
                 // Wave 0 walks its own chunks (the first 1024 samples, where the windows are still filling); waves 1..15
                 // take the queue in blocks of 64, those that share a SIMD with wave 0 (4, 8, 12) last.
                 if (tid < 64) {
@@ -449,7 +461,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             }
         }
         STAMP(13);
-        __syncthreads();  // B5
+        slot_sync<G>();  // B5
         STAMP(14);
         pending = cand;
         pending_k0 = k0;
@@ -480,15 +492,15 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 #pragma unroll
         for (int i = 0; i < G::CH; ++i) sh.u[i * G::T + tid] &= 0x3FFFFFFFu;
         clear_partition_scratch();
-        __syncthreads();
+        slot_sync<G>();
     } else {
         phase_r(th, sh, best);  // last reader of the staged samples; leaves the plain residual in sh.u
         ScanRegs<G> sr;
         scan_pz_part1(sh, tid, sr);
-        __syncthreads();
+        slot_sync<G>();
         clear_partition_scratch();
         scan_pz_part2(sh, tid, sr);
-        __syncthreads();
+        slot_sync<G>();
     }
     const bool pnarrow = sh.tabP[G::T] < kNarrowLimit;
     STAMP(16);
@@ -508,19 +520,19 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             }
             if (tid < 15) pm.grp[tid][G::NG] = 0;  // the slot past the last group (the scan's total)
         }
-        __syncthreads();
+        slot_sync<G>();
         {
             constexpr int NW = G::T / 64;
             const int wave = tid >> 6, lane = tid & 63;
             for (int w = wave; w < 15; w += NW) wave_exclusive_scan_u32(pm.grp[w], G::NG + 1, lane);
         }
-        __syncthreads();
+        slot_sync<G>();
         STAMP(17);
         for (int idx = tid; idx < (LACX_HOOK(prm, 32u) ? 0 : nseg); idx += G::T) {
             const int p = 31 - __clz(idx + 2);
             seg_static_eval(sh, n, p, (uint32_t)(idx + 2 - (1 << p)));
         }
-        __syncthreads();
+        slot_sync<G>();
         STAMP(18);
         auto flush = [&pm](uint32_t idx, unsigned long long rc, unsigned long long bn, unsigned long long zr,
                            uint32_t hr) {
@@ -624,7 +636,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             }
         }
         STAMP(19);
-        __syncthreads();
+        slot_sync<G>();
         STAMP(20);
         // Segment idx of order p has idx + 2 in [2^p, 2^(p+1)): walking j = idx + 2 in chunks of 64 gives every wave
         // from j = 64 on segments of ONE order -- one atomic per wave there instead of 64 on one address.
@@ -639,10 +651,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                 atomicAdd(&pm.pbits[31 - __clz(j)], bits);
             }
         }
-        __syncthreads();
+        slot_sync<G>();
     }
     if (tid == 0) finalize_plan(sh, n, prm.zero_run, max_p, &sh.plan);
-    __syncthreads();
+    slot_sync<G>();
     // only the head and the partitions in use: the rest of the record is zero already (the plans are cleared per call)
     const int plan_words = (int)(offsetof(ChannelPlan, part_mode_k) + ((size_t)1 << sh.plan.partition_order) + 3) / 4;
     for (int i = tid; i < plan_words; i += G::T)
@@ -669,18 +681,29 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 #ifndef LACX_PROBE_WAVES
 #define LACX_PROBE_WAVES 6
 #endif
+// Probe class: one wave per probe slot, one slot per workgroup.  (Measured against the twelve probe slots of a block as
+// the twelve waves of ONE workgroup -- independent, no workgroup barrier (slot_sync), but started together so that the
+// instruction stream is fetched once for twelve waves: white noise, every block probed, 0.69 -> 0.65 ms; music, 28 % of
+// the blocks probed, 0.18 -> 0.26 ms, because 492 twelve-wave workgroups balance worse over 256 CUs than 5 904 single
+// waves.  LACX_PROBE_WG_WAVES=12 rebuilds that form.)
+#ifndef LACX_PROBE_WG_WAVES
+#define LACX_PROBE_WG_WAVES 1
+#endif
+constexpr int kProbeWaves = LACX_PROBE_WG_WAVES;
 template <class G>
-__global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
+__global__ __launch_bounds__(G::T == 64 ? 64 * kProbeWaves : G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
                                                   const uint32_t* __restrict__ need,
                                                   ChannelPlan* __restrict__ plans,
                                                   unsigned long long* __restrict__ t_first,
                                                   unsigned long long* __restrict__ t_last, FuseArgs fuse,
                                                   uint32_t* __restrict__ work_ctr, uint32_t total_wg, uint32_t pair_blocks) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_all[];
     __shared__ uint32_t s_next;
     __shared__ PendingSlot s_pend;
-    const int tid = threadIdx.x;
+    static_assert(sizeof(Smem<G>) % 16 == 0, "slot images are 16-byte aligned");
+    const int tid = G::T == 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    unsigned char* smem_raw = smem_all + (G::T == 64 ? (size_t)(threadIdx.x >> 6) * sizeof(Smem<G>) : 0);
     // the earliest start, kept inverted (the word starts as zero like everything else the call clears)
     if (t_first && tid == 0) atomicMax(t_first, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     // Persistent form (work_ctr != nullptr; whole-block class only): one workgroup per CU takes virtual workgroup ids from
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_ana
     // blocks of the stream are handed out slot by slot (units pair_blocks ..), so that the tail of the kernel is balanced
     // in single slots as before.
     uint32_t rep = 0;         // channel slot of a pair unit
-    uint32_t v = blockIdx.x;  // virtual workgroup id
+    uint32_t v = G::T == 64 ? blockIdx.x * (uint32_t)kProbeWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : blockIdx.x;  // virtual workgroup id
     if (persistent) {
         if (tid == 0) {
             s_next = atomicAdd(work_ctr, 1u);
@@ -844,7 +867,7 @@ hipError_t ensure_kernel_attrs() {
     if (e == hipSuccess) e = set_kernel_attrs_front();
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_analyze<GProbe>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem<GProbe>));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Smem<GProbe>) * kProbeWaves));
     if (e == hipSuccess) e = set_kernel_attrs_emit();
     if (e == hipSuccess) done[dev] = true;
     return e;
@@ -895,7 +918,8 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
         total_wg += p.num_blocks * (p.channels == 2 ? 2u : 1u);
     }
     if (any_auto) {
-        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * 12u), dim3(GProbe::T), sizeof(Smem<GProbe>), stream, br, 1, 0u, 0,
+        static_assert(12 % kProbeWaves == 0, "whole workgroups per block");
+        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * (12u / kProbeWaves)), dim3(GProbe::T * kProbeWaves), sizeof(Smem<GProbe>) * kProbeWaves, stream, br, 1, 0u, 0,
                            ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
                            (uint32_t*)nullptr, 0u, 0u);
         hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
