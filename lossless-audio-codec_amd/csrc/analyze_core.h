@@ -217,6 +217,7 @@ struct PartMem {
     // partition_quick: (chunk, order) pairs whose Rice parameter is not provably constant over the chunk, left to
     // partition_slow_entry; entry = chunk | (order - 1) << 12.  One region of 64 * MAXP entries per wave.
     uint32_t qcount;  // (host simulator only)
+    uint32_t wqcount[16];  // entries every wave has queued (the queued pairs are then walked by all waves in equal shares)
     uint16_t queue[G::T * G::MAXP];
 };
 
@@ -997,13 +998,16 @@ LACX_HD void phase_b_dispatch(Thread<G>& th, const Smem<G>& sh, uint32_t k0, boo
     phase_b_dispatch<G>(th, sh, k0, narrow, zr, full, G::T > 64 && th.tid >= 64 && 64 * G::CH >= 256);
 }
 
+#ifndef LACX_QUEUED_STEADY
+#define LACX_QUEUED_STEADY 1
+#endif
 // The walk of chunk t (t >= 64: the steady instance) by whichever lane the queue of phase B hands it to; the chunk's
 // costs are added to the lane's own.
 template <class G>
 LACX_HD void phase_b_queued(Thread<G>& th, const Smem<G>& sh, int t, uint32_t k0, bool narrow, bool zr, bool full) {
     Thread<G> c;
     thread_init(c, th.n, t);
-    phase_b_dispatch<G>(c, sh, k0, narrow, zr, full, true);
+    phase_b_dispatch<G>(c, sh, k0, narrow, zr, full, LACX_QUEUED_STEADY != 0);
     th.crice += c.crice;
     th.cbin += c.cbin;
     th.czr += c.czr;

@@ -619,10 +619,45 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
                     else partition_quick_costs<G>(th, sh, max_p, qp, flush32, enqueue);
                 }
                 STAMP(7);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS stores, before it reads them back
-                for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) {
-                    if (with_zr) partition_slow_entry<G, true>(sh, n, wq[e], flush_entry);
-                    else partition_slow_entry<G, false>(sh, n, wq[e], flush_entry);
+                // The queued pairs cluster where partitions begin (the prefix mean still moves there), so the waves' queues
+                // differ severalfold in length and, walked wave by wave, the longest one kept the other fifteen waves
+                // waiting at the barrier behind the search.  One barrier here instead: every wave publishes its count, and
+                // the pairs of ALL queues are walked in equal shares -- entry e of the concatenated queues by thread e % T.
+                if constexpr (G::T > 64) {
+                    constexpr int NW = G::T / 64;
+                    static_assert(NW <= 16, "one count per wave");
+                    const int lane = tid & 63;
+                    if (lane == 0) pm.wqcount[tid >> 6] = queued;
+                    __syncthreads();
+                    const uint32_t mine = lane < NW ? pm.wqcount[lane] : 0u;
+                    const uint32_t incl = wave_scan_add_u32(mine);             // lanes 0..NW-1: entries up to and including wave `lane`
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, NW - 1);
+                    for (uint32_t e0 = (uint32_t)(tid & ~63); e0 < total; e0 += (uint32_t)G::T) {  // wave-uniform trip count:
+                        // every lane takes part in the shuffles (a disabled source lane would read as zero)
+                        const bool live = e0 + (uint32_t)lane < total;
+                        const uint32_t e = live ? e0 + (uint32_t)lane : total - 1u;
+                        // the wave whose queue holds entry e: the first w with incl[w] > e (four shuffle steps over 16 lanes)
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int step = NW / 2; step >= 1; step >>= 1) {
+                            const uint32_t probe = (uint32_t)__shfl((int)incl, (int)(w + (uint32_t)step - 1u), 64);
+                            w += probe <= e ? (uint32_t)step : 0u;
+                        }
+                        // (unconditional: under a per-lane condition the source lanes that skip it would read as zero)
+                        const uint32_t prev = (uint32_t)__shfl((int)incl, (int)(w ? w - 1u : 0u), 64);
+                        const uint32_t before = w ? prev : 0u;
+                        const uint32_t entry = pm.queue[w * 64u * (uint32_t)G::MAXP + (e - before)];
+                        if (live) {
+                            if (with_zr) partition_slow_entry<G, true>(sh, n, entry, flush_entry);
+                            else partition_slow_entry<G, false>(sh, n, entry, flush_entry);
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS stores, before it reads them back
+                    for (uint32_t e = (uint32_t)(tid & 63); e < queued; e += 64u) {
+                        if (with_zr) partition_slow_entry<G, true>(sh, n, wq[e], flush_entry);
+                        else partition_slow_entry<G, false>(sh, n, wq[e], flush_entry);
+                    }
                 }
                 STAMP(9);
             }
