@@ -194,9 +194,12 @@ __device__ __forceinline__ uint64_t scan_pz_part2(M& sh, int tid, const ScanRegs
 // the highest set bit in the wave are skipped.  Lanes 0..29 then add their plane's count to the block totals.
 // (Measured against an all-vector form -- two planes per word, unpacked per lane and summed on the DPP network: that
 // one took a quarter longer; here the scalar unit is not the bottleneck, unlike in pass 1.)
+// first_plane (wave-uniform): planes below it are not needed for the block totals (the static parameters that can still
+// win are all >= first_plane, static_k_candidates64); wave 0 still counts them for the first 256 samples, whose
+// initial-k estimate looks at every k <= 12.
 template <class G>
 __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t* planeTot, uint32_t* planeTot256,
-                                                  int tid) {
+                                                  int tid, int first_plane = 0) {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t any = 0;
 #pragma unroll
@@ -206,7 +209,7 @@ __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t*
     const uint64_t m256 = (G::W256 >= 64) ? ~0ull : ((1ull << (G::W256 & 63)) - 1ull);
     uint32_t mine = 0, mine256 = 0;
     const bool first256 = wave == 0;  // only wave 0 holds samples of the first 256 (uniform)
-    for (int b = 0; b < nplanes; ++b) {
+    for (int b = first256 ? 0 : first_plane; b < nplanes; ++b) {
         uint32_t tot = 0, tot256 = 0;
 #pragma unroll
         for (int l = 0; l < G::LV; ++l) {
@@ -220,7 +223,7 @@ __device__ __forceinline__ void plane_totals_wave(const Thread<G>& th, uint32_t*
         }
     }
     if (lane < nplanes) {
-        atomicAdd(&planeTot[lane], mine);
+        if (lane >= first_plane) atomicAdd(&planeTot[lane], mine);
         if (wave == 0) atomicAdd(&planeTot256[lane], mine256);
     }
 }
@@ -268,12 +271,12 @@ __device__ __forceinline__ void ksums_wave(const Thread<G>& th, uint32_t* ksum, 
 //   (S - n (2^k - 1)) / 2^k <= A_k <= S >> k,
 // so a k whose lower cost bound exceeds the smallest upper bound over all k can neither be the minimum nor tie with it.
 // Typically four of the sixteen remain (k* - 1 .. k* + 2 around S / n).  Returns the mask of the k to evaluate.
-__device__ __forceinline__ uint32_t static_k_candidates(uint32_t S, uint32_t n, int lane) {
+__device__ __forceinline__ uint32_t static_k_candidates(uint64_t S, uint32_t n, int lane) {
     const uint32_t k = (uint32_t)lane & 15u;
     const uint64_t fixed = (uint64_t)n * (1u + k);
-    const uint64_t upper = (uint64_t)(S >> k) + fixed;
+    const uint64_t upper = (S >> k) + fixed;
     const uint64_t slack = (uint64_t)n * ((1u << k) - 1u);
-    const uint64_t lower = ((uint64_t)S > slack ? (((uint64_t)S - slack + ((1u << k) - 1u)) >> k) : 0ull) + fixed;
+    const uint64_t lower = (S > slack ? ((S - slack + ((1u << k) - 1u)) >> k) : 0ull) + fixed;
     const uint64_t umin = wave_last_u64(wave_scan_min_u64(lane < 16 ? upper : ~0ull));
     return (uint32_t)__ballot(lane < 16 && lower <= umin) & 0xFFFFu;
 }

@@ -139,10 +139,11 @@ __device__ __forceinline__ void score_candidate_wave(Smem<G>& sh, int cand, uint
     if (ksums) {  // planeTot[k] = sum_j (u_j >> k) already (ksums_wave), for the k of kmask (the others cannot win)
         if (lane < 16 && ((kmask >> lane) & 1u)) key = (((uint64_t)planeTot[lane] + (uint64_t)n * (uint64_t)(1 + lane)) << 4) | (uint64_t)lane;
     } else {
+        // (planes below the lowest k of kmask were not counted: the suffix sums T_k of the k in the mask do not need them)
         const int b = 29 - lane;
         const uint64_t w = (lane < 30) ? ((uint64_t)planeTot[b] << b) : 0ull;
         const uint64_t tk = wave_scan_add_u64(w);  // lane l: T_(29-l)
-        if (lane >= 14 && lane < 30) key = (((tk >> b) + (uint64_t)n * (uint64_t)(1 + b)) << 4) | (uint64_t)b;  // cost < 2^45
+        if (lane >= 14 && lane < 30 && ((kmask >> b) & 1u)) key = (((tk >> b) + (uint64_t)n * (uint64_t)(1 + b)) << 4) | (uint64_t)b;  // cost < 2^45
     }
     const uint64_t best_key = wave_last_u64(wave_scan_min_u64(key));
     if (lane == 0) {
@@ -371,9 +372,10 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         const bool narrow = total_u < kNarrowLimit;  // all prefix sums fit 32 bits (uniform)
         const bool ksums = narrow && !LACX_HOOK(prm, 262144u);
         // (the k whose static cost can still be the smallest follow from the block's sum alone: about four of sixteen)
-        const uint32_t kmask = (ksums && !LACX_HOOK(prm, 1048576u)) ? static_k_candidates((uint32_t)total_u, n, tid & 63) : 0xFFFFu;
+        const uint32_t kmask = !LACX_HOOK(prm, 1048576u) ? static_k_candidates(total_u, n, tid & 63) : 0xFFFFu;
         if (!LACX_HOOK(prm, 1u)) {
-            if (ksums) ksums_wave(th, pt, pt256, tid, kmask); else plane_totals_wave(th, pt, pt256, tid);
+            if (ksums) ksums_wave(th, pt, pt256, tid, kmask);
+            else plane_totals_wave(th, pt, pt256, tid, kmask ? (int)__builtin_ctz(kmask) : 0);
         }
         // the first 256 samples all belong to wave 0: its own totals are complete once its atomics are (same wave,
         // program order), so it can derive the initial k at once; every other thread reads it after B3
