@@ -902,15 +902,15 @@ def worker(args) -> int:
             for _ in range(warmup):
                 run()
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            with StepLog() as log:
+            with StepLog() as log:  # (collects garbage once on entry: outside the timed loop)
+                t1 = time.perf_counter()
                 for _ in range(steps):
                     log.begin()
                     res, kernel_ms, tms = run()
                     log.end(tms)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / steps
             each = log.rows["wall_ms"]
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / steps
             ok = True
             for j, (pay, tab) in zip(jobs, res):
                 lac = lac_of(pay.tobytes(), np.array(tab, dtype=np.uint32), j["sr"], j["bd"], j["sm"], j["ch"])

@@ -28,6 +28,14 @@ Knobs read_knobs() {
     k.persistent = !set("LACX_NO_PERSISTENT");
     k.debug_drain = set("LACX_DEBUG_DRAIN");
     k.two_copy_streams = !set("LACX_ONE_COPY_STREAM");
+    if (const char* v = std::getenv("LACX_STREAM_PRIO")) {  // "main,chunks,pack", each -1 (high) / 0 (normal) / 1 (low)
+        int a = 0, b = 0, c = 0;
+        if (std::sscanf(v, "%d,%d,%d", &a, &b, &c) == 3) {
+            k.prio_main = a;
+            k.prio_chunks = b;
+            k.prio_pack = c;
+        }
+    }
     k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
     k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
     k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");
@@ -86,15 +94,25 @@ int ensure_device(lacx_encoder* e) {
     HIP_TRY(e, hipSetDevice(dev), "hipSetDevice");
     e->device = dev;
     {
-        // Pipeline chunk c runs on stream c: earlier chunks get the higher priority so that they finish their
-        // analysis first and their emit (PCIe-bound) runs under the later chunks' analysis.
+        // Stream priorities.  The HIP runtime multiplexes streams onto a small pool of hardware queues PER PRIORITY LEVEL,
+        // and commands of streams that share a hardware queue execute in order.  The streaming packer must therefore be
+        // alone on its level: behind the analysis kernel in a shared queue it starts when the analysis is over (every
+        // encoder of a process but the first few: drain_first_ms 4.4 instead of 0.9 ms, steps 50 % longer -- the round-4
+        // bench caught it); sharing a queue with the uploader's stream it deadlocks against the upload it waits for until
+        // its 20 ms bound expires (a test caught that).  So: the analysis streams (pipeline chunk c on stream c) at HIGH
+        // priority (front kernels measured 20 % slower at normal), the packer at LOW, where no other stream of this
+        // library or, by default, of anybody else lives; copy, upload and decoder streams at the default (normal).
+        // Measured (WAV -> .lac, 10 min stream, 4 chunks): high/high/low 3.42 ms, high/low/normal 3.40, high/normal/low
+        // 3.73, all high (round 3) 3.41.  LACX_STREAM_PRIO=main,chunks,pack overrides.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const bool prio = e->knobs.stream_priority && greatest < least;
+        const int normal = (greatest + least) / 2 > greatest ? (greatest + least) / 2 : std::min(greatest + 1, least);
+        auto level = [&](int code) { return code < 0 ? greatest : (code == 0 ? normal : least); };  // -1 high, 0 normal, 1 low
         int i = 0;
         for (auto& s : e->stream) {
             if (prio) {
-                const int p = std::min(greatest + i, least);
+                const int p = level(i == 0 ? e->knobs.prio_main : e->knobs.prio_chunks);
                 HIP_TRY(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p), "hipStreamCreate");
             } else {
                 HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
@@ -112,7 +130,9 @@ int ensure_device(lacx_encoder* e) {
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIP_TRY(e, hipStreamCreateWithPriority(&e->pack_stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
+        const int normal = (greatest + least) / 2 > greatest ? (greatest + least) / 2 : std::min(greatest + 1, least);
+        const int pp = e->knobs.prio_pack < 0 ? greatest : (e->knobs.prio_pack == 0 ? normal : least);
+        HIP_TRY(e, hipStreamCreateWithPriority(&e->pack_stream, hipStreamNonBlocking, pp), "hipStreamCreate");
     }
     HIP_TRY(e, hipEventCreateWithFlags(&e->pack_done, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -325,10 +345,11 @@ std::vector<Chunk> plan_chunks(const Knobs& kn, uint32_t nb, bool device_emit, b
     // 2 h shard).  With the fused emit + streaming packer nothing is left to overlap by chunking -- the payload leaves
     // while the analysis runs, and ingest / probes keep every CU busy by themselves -- and one launch set measured best
     // from 10 min to 2 h of audio (a chunked run only adds kernel boundaries).
-    // With the input still in host memory the chunks pipeline the upload: three chunks of relative size 1 : 3 : 4 -- a
-    // small first one, so that little of the H2D copy is exposed before the first kernel (measured, 10 min stream, WAV
-    // image -> .lac: 4 equal chunks 4.36 ms, 1:2:3:3 4.17, 1:2:3 4.17, 1:3:4 4.11, 2:3:4 4.21, 6 or 8 equal 4.6).
-    const uint32_t dev_chunks = fused ? (upload ? 3u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
+    // With the input still in host memory the chunks pipeline the upload (the uploader thread copies chunk c + 1 while
+    // chunk c's kernels are enqueued and run): four equal chunks measured best once the copies came from their own thread
+    // and the packer's stream had a priority level of its own (10 min stream, WAV image -> .lac: 3.40 ms; 1:2:3 3.57,
+    // 1:3:4 3.6, one chunk 4.65; round 3, copies issued by the calling thread: 1:3:4 3.75).
+    const uint32_t dev_chunks = fused ? (upload ? 4u : 1u) : (nb >= 12000u ? 6u : (nb >= 6000u ? 4u : 3u));
     nchunks = std::max(1u, std::min(nchunks, device_emit ? dev_chunks : 8u));
     bool forced = false;
     if (kn.pipe_chunks >= 1 && kn.pipe_chunks <= (uint32_t)kMaxChunks) {  // tuning knob

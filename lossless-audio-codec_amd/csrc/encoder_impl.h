@@ -54,6 +54,10 @@ using namespace lacx_host;
 // point reads the environment afterwards.  All are tuning / diagnostic switches; none changes the bytes produced.
 struct Knobs {
     bool stream_priority = true;   // LACX_NO_STREAM_PRIORITY unset
+    // LACX_STREAM_PRIO=main,chunks,pack: priority level (-1 high, 0 normal, 1 low) of the first analysis stream, of the
+    // later pipeline chunks' streams and of the streaming packer's stream.  The packer's level must be one that NOTHING
+    // else uses: hardware queues are pooled per level (see ensure_device).
+    int prio_main = -1, prio_chunks = -1, prio_pack = 1;
     bool fused_emit = true;        // LACX_FUSED_EMIT != 0
     bool emit_staged = false;      // LACX_EMIT_STAGED
     bool direct_packer = false;    // LACX_DIRECT_PACKER: the packer stores into pinned host memory itself (round-2 layout)
