@@ -9,7 +9,7 @@ shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-ARGS="--no-cpu-baseline --no-end-to-end --no-other-workloads $@"
+ARGS="--no-cpu-baseline --no-end-to-end --no-other-workloads --no-decode-check $@"
 B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $ARGS"
 run() {  # name, env prefix vars..., then rocprof args
   local name=$1; shift
@@ -30,6 +30,7 @@ export LACX_PIPE_CHUNKS=1
 run sq1 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq2 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run grbm --pmc GRBM_GUI_ACTIVE
+run ic1 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ SQ_IFETCH
 unset LACX_PIPE_CHUNKS
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE

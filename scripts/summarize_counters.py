@@ -117,7 +117,10 @@ if default and derived:
             "fetch_size_kb_per_launch": f,
             "write_size_kb_per_launch": w,
             "traffic_bytes_per_launch": int(2 * f * 1024 + w * 1024),
-            "algorithmic_bytes_per_launch": int((28_800_000 * 2 * 2 + 2 * blocks * 296 + 72_573_825) / launches),
+            "algorithmic_bytes_per_launch": int((28_800_000 * 2 * 2 + 2 * blocks * 296) / launches),
+            "algorithmic_bytes_incl_bitstream_per_launch": int((28_800_000 * 2 * 2 + 2 * blocks * 296 + 72_573_825) / launches),
+            "traffic_ratio": round((2 * f * 1024 + w * 1024) / ((28_800_000 * 2 * 2 + 2 * blocks * 296) / launches), 3),
             "note": "KB -> bytes x1024; FETCH_SIZE x2 (16-byte streaming reads on gfx950, MI355X_MICROARCH.md), WRITE_SIZE as is. "
-                    "Algorithmic: PCM once + plan records + the 72.57 MB of bitstream the fused emit writes once.",
+                    "Algorithmic (SURVEY 8d): PCM at its source depth once + plan records; the fused emit writes the 72.57 MB of "
+                    "bitstream once as well (the *_incl_bitstream figure).",
         }, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
