@@ -36,6 +36,7 @@ Knobs read_knobs() {
             k.prio_pack = c;
         }
     }
+    k.front_halves = !set("LACX_NO_FRONT_HALVES");
     k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
     k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
     k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");
@@ -112,7 +113,8 @@ int ensure_device(lacx_encoder* e) {
         int i = 0;
         for (auto& s : e->stream) {
             if (prio) {
-                const int p = level(i == 0 ? e->knobs.prio_main : e->knobs.prio_chunks);
+                // (the last stream doubles as the low-priority stream of the second half's front kernels, LaunchTuning::aux_stream)
+                const int p = level(i == 0 ? e->knobs.prio_main : (i == kStreams - 1 ? 1 : e->knobs.prio_chunks));
                 HIP_TRY(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p), "hipStreamCreate");
             } else {
                 HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
@@ -125,6 +127,7 @@ int ensure_device(lacx_encoder* e) {
     for (auto& ev : e->done) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     for (auto& ev : e->copied) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipEventCreateWithFlags(&e->prologue, hipEventDisableTiming), "hipEventCreate");
+    for (auto& ev : e->aux_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 4), 0), "hipHostMalloc");
     {
@@ -549,6 +552,8 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         for (auto& ev : e->copied)
             if (ev) (void)hipEventDestroy(ev);
         if (e->prologue) (void)hipEventDestroy(e->prologue);
+        for (auto& ev : e->aux_ev)
+            if (ev) (void)hipEventDestroy(ev);
         if (e->pack_done) (void)hipEventDestroy(e->pack_done);
         if (e->pack_stream) (void)hipStreamDestroy(e->pack_stream);
         if (e->d_payload) (void)hipFree(e->d_payload);

@@ -429,6 +429,11 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         if (chunks.size() > 1 || !kn.persistent) wl.work_ctr = nullptr;
         LaunchTuning tune = kn.tune;
         if (front_split) tune.front_stream = e->front_stream;
+        if (kn.front_halves && chunks.size() == 1 && s != e->stream[kStreams - 1]) {  // (see LaunchTuning::aux_stream)
+            tune.aux_stream = e->stream[kStreams - 1];
+            tune.aux_ev[0] = e->aux_ev[0];
+            tune.aux_ev[1] = e->aux_ev[1];
+        }
         HIP_TRY(e, launch_analysis(bind(ls), wl, s, e->ev[c], &fa, chain ? e->ev[c - 1][3] : nullptr, tune), "kernel launch");
         if (c == 0 && fuse_items && kn.packer) {
             // the streaming packer: beside the whole-block analysis kernels, on its own stream.  It starts when the first

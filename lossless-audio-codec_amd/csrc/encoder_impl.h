@@ -72,6 +72,7 @@ struct Knobs {
     uint32_t pipe_chunks = 0;      // LACX_PIPE_CHUNKS
     std::string pipe_split;        // LACX_PIPE_SPLIT
     uint32_t drain_fence = 0;      // LACX_DRAIN_FENCE
+    bool front_halves = true;      // LACX_NO_FRONT_HALVES unset: a one-chunk shard's front kernels in two block halves on two streams
     bool front_stream_split = false; // LACX_FRONT_STREAM: upload pipeline with the front kernels on a high-priority stream (experiment)
     uint32_t fanout_exchange = 0;  // LACX_FANOUT_EXCHANGE: 0 auto (RCCL where the devices are distinct), 1 host, 2 rccl
     LaunchTuning tune;             // LACX_PERSISTENT_GRID, LACX_PACK_NAP, LACX_PACK_GRID
@@ -175,6 +176,7 @@ struct lacx_encoder {
         int layout = 0;
     } pend;
     hipEvent_t prologue = nullptr;  // per-call memsets done (the chunk streams wait for it)
+    hipEvent_t aux_ev[2] = {};      // front kernels in two halves (LaunchTuning::aux_ev)
     hipStream_t pack_stream = nullptr;  // the streaming packer of the fused emit runs here, beside the analysis
     hipEvent_t pack_done = nullptr;
     uint8_t* slots = nullptr;  // staging slots of the fused emit (device memory)

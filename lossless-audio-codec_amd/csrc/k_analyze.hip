@@ -937,12 +937,6 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     if (ev) (void)hipEventRecord(ev[0], stream);
     e = hipMemsetAsync(ws.plans, 0, sizeof(ChannelPlan) * (size_t)nb * kSlotsPerBlock, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ingest, dim3(nb * 4u), dim3(kIngestThreads), 0, stream, br, ws.sums, ws.badidx, ws.acorr);
-    hipLaunchKernelGGL(k_stereo, dim3((nb + 3) / 4), dim3(64), 0, stream, br, ws.sums, ws.badidx, ws.bplans,
-                       ws.need_probe, ws.need_full);
-    hipLaunchKernelGGL(k_levinson, dim3((nb * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
-                       sizeof(LevMem), stream, br, ws.acorr, ws.need_probe, ws.lpcs);
-    if (ev) (void)hipEventRecord(ev[1], stream);
     // per-block stereo in any stream of the set: probes + decision; a final block of <= 4096 frames of such a stream can
     // need all four channels (full LR-vs-MS comparison, ref lac/encoder.cpp:336-340)
     bool any_auto = false, any_both = false;
@@ -954,13 +948,62 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
         any_both = any_both || (autost && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit);
         total_wg += p.num_blocks * (p.channels == 2 ? 2u : 1u);
     }
-    if (any_auto) {
-        static_assert(12 % kProbeWaves == 0, "whole workgroups per block");
-        hipLaunchKernelGGL(k_analyze<GProbe>, dim3(nb * (12u / kProbeWaves)), dim3(GProbe::T * kProbeWaves), sizeof(Smem<GProbe>) * kProbeWaves, stream, br, 1, 0u, 0,
-                           ws.lpcs, ws.need_probe, ws.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
-                           (uint32_t*)nullptr, 0u, 0u);
-        hipLaunchKernelGGL(k_decide, dim3((nb + 3) / 4), dim3(64), 0, stream, br, 1, ws.bplans, ws.need_probe,
-                           ws.need_full, ws.plans);
+    // the front kernels of the blocks [b0, b0 + cnt) of a one-stream set: ingest, stereo estimate, Levinson, probes, decision
+    auto launch_front = [&](const BatchRef& r, const DeviceWorkspace& w, uint32_t cnt, hipStream_t st, bool mark) {
+        hipLaunchKernelGGL(k_ingest, dim3(cnt * 4u), dim3(kIngestThreads), 0, st, r, w.sums, w.badidx, w.acorr);
+        hipLaunchKernelGGL(k_stereo, dim3((cnt + 3) / 4), dim3(64), 0, st, r, w.sums, w.badidx, w.bplans, w.need_probe, w.need_full);
+        hipLaunchKernelGGL(k_levinson, dim3((cnt * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
+                           sizeof(LevMem), st, r, w.acorr, w.need_probe, w.lpcs);
+        if (mark && ev) (void)hipEventRecord(ev[1], st);
+        if (any_auto) {
+            static_assert(12 % kProbeWaves == 0, "whole workgroups per block");
+            hipLaunchKernelGGL(k_analyze<GProbe>, dim3(cnt * (12u / kProbeWaves)), dim3(GProbe::T * kProbeWaves), sizeof(Smem<GProbe>) * kProbeWaves, st, r, 1, 0u, 0,
+                               w.lpcs, w.need_probe, w.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
+                               (uint32_t*)nullptr, 0u, 0u);
+            hipLaunchKernelGGL(k_decide, dim3((cnt + 3) / 4), dim3(64), 0, st, r, 1, w.bplans, w.need_probe, w.need_full, w.plans);
+        }
+    };
+    const bool halves = tune.aux_stream && tune.aux_ev[0] && tune.aux_ev[1] && br.table == nullptr && ls.nstreams == 1 && nb >= 1024u;
+    if (halves) {
+        const AnalyzeParams& p = br.single.prm;
+        const uint32_t nb1 = (nb / 2u) & ~7u;  // (whole groups of eight blocks: the XCD-aware numbering of k_ingest)
+        const uint64_t frame_bytes = p.layout == PCM_INTERLEAVED_I16 ? 2ull * (uint64_t)p.channels
+                                                                     : (p.layout == PCM_INTERLEAVED_I24 ? 3ull * (uint64_t)p.channels : 4ull);
+        auto sub = [&](uint32_t b0, uint32_t cnt) {
+            BatchRef r = br;
+            StreamDesc& sd = r.single;
+            const uint64_t f0 = (uint64_t)b0 * kMaxBlock;
+            const uint64_t f1 = p.frames < (uint64_t)(b0 + cnt) * kMaxBlock ? p.frames : (uint64_t)(b0 + cnt) * kMaxBlock;
+            sd.prm.frames = f1 - f0;
+            sd.prm.num_blocks = cnt;
+            r.total_blocks = cnt;
+            sd.left = reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(br.single.left) + f0 * frame_bytes);
+            sd.right = (p.layout == PCM_PLANAR_I32 && br.single.right) ? br.single.right + f0 : nullptr;
+            return r;
+        };
+        auto wsub = [&](uint32_t b0) {
+            DeviceWorkspace w = ws;
+            const size_t sl = (size_t)b0 * kSlotsPerBlock;
+            w.plans += sl;
+            w.bplans += b0;
+            w.need_probe += b0;
+            w.need_full += b0;
+            w.acorr += sl * 13;
+            w.lpcs += sl;
+            w.sums += (size_t)b0 * 12;
+            w.badidx += (size_t)b0 * 2;
+            return w;
+        };
+        hipError_t he = hipEventRecord(tune.aux_ev[0], stream);  // behind the memset and whatever the caller queued before
+        if (he == hipSuccess) he = hipStreamWaitEvent(tune.aux_stream, tune.aux_ev[0], 0);
+        if (he != hipSuccess) return he;
+        launch_front(sub(0, nb1), ws, nb1, stream, true);
+        launch_front(sub(nb1, nb - nb1), wsub(nb1), nb - nb1, tune.aux_stream, false);
+        he = hipEventRecord(tune.aux_ev[1], tune.aux_stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(stream, tune.aux_ev[1], 0);
+        if (he != hipSuccess) return he;
+    } else {
+        launch_front(br, ws, nb, stream, true);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     if (full_stream != stream) {

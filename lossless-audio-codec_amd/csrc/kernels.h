@@ -56,6 +56,12 @@ struct LaunchTuning {
     // pipeline with a high-priority front stream: the next chunk's front kernels -- short, latency-bound -- then take the
     // CUs that the current chunk's whole-block workgroups free one by one instead of waiting for the end of that kernel.
     hipStream_t front_stream = nullptr;
+    // One stream's front kernels in two block halves (one launch set = one stream, >= 1024 blocks): the first half on the
+    // launch's stream, the second on `aux_stream` (lower priority, so that it starts when the first half's ingest kernel
+    // has been dispatched): the Levinson kernel of a half -- one wave per SIMD, latency-bound, the chip nearly idle -- then
+    // runs beside the other half's ingest / probe kernels instead of alone.  aux_ev: two events of the caller's.
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
 };
 
 // Progress reporting of the streaming packer for a device destination that the host drains with a copy engine while
