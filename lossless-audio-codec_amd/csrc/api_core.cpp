@@ -113,8 +113,10 @@ int ensure_device(lacx_encoder* e) {
         int i = 0;
         for (auto& s : e->stream) {
             if (prio) {
-                // (the last stream doubles as the low-priority stream of the second half's front kernels, LaunchTuning::aux_stream)
-                const int p = level(i == 0 ? e->knobs.prio_main : (i == kStreams - 1 ? 1 : e->knobs.prio_chunks));
+                // (the last stream doubles as the lower-priority stream of the second half's front kernels,
+                // LaunchTuning::aux_stream: NORMAL, not low -- the packer must stay alone on its level, see above; two
+                // encoders on one device whose fourth pipeline chunk shared a hardware queue with a packer stalled 20 ms)
+                const int p = level(i == 0 ? e->knobs.prio_main : (i == kStreams - 1 ? 0 : e->knobs.prio_chunks));
                 HIP_TRY(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p), "hipStreamCreate");
             } else {
                 HIP_TRY(e, hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
