@@ -37,6 +37,7 @@ Knobs read_knobs() {
         }
     }
     k.front_halves = !set("LACX_NO_FRONT_HALVES");
+    k.lazy_repair = !set("LACX_NO_LAZY_REPAIR");
     k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
     k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
     k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");

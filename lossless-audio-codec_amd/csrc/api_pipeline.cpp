@@ -476,6 +476,10 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         const DeviceWorkspace& w = cx.w;
         // block offsets are global: chunk c starts where chunk c-1 ended (its k_offsets must have run)
         const bool packer_counts = fuse_items && kn.packer;
+        // Lazy repair: a one-chunk shard whose channel blocks all take part in the fused emit normally leaves k_pack and
+        // k_emit nothing to do; they are not even enqueued, the gather kernel checks the packer's count and the host
+        // enqueues them afterwards in the rare case (a packer wave that gave up, a bitstream longer than its slot).
+        const bool lazy = kn.lazy_repair && packer_counts && chunks.size() == 1 && fuse_items == nb * (uint32_t)channels;
         (void)cl;
         (void)cr;
         (void)prm;
@@ -483,7 +487,8 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         HIP_TRY(e, launch_emit(bind(ls), w, emit_dst, prev_end, c ? e->copied[c - 1] : nullptr,
                                e->copied[c], s, true, packer_counts ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
                                nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr,
-                               e->ws.err_flag + kMaxChunks + 3), "emit launch");
+                               e->ws.err_flag + kMaxChunks + 3, lazy), "emit launch");
+        e->pend.lazy_repair = lazy;
         prev_end = w.block_off + ck.count;
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
         // what the host reads afterwards, in one kernel that stores into the pinned buffers
@@ -521,6 +526,9 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
     if (!(drained && fused && fuse_items != 0)) e->pend.ranges = 0;
     for (int i = 0; i < kStreams; ++i) e->pend.st[i] = st[i];
     e->pend.front_split = front_split;
+    e->pend.fuse_items = fuse_items;
+    e->pend.emit_cap = emit_cap;
+    e->pend.emit_dst = emit_dst;
     e->pend.t0 = t0;
     e->pend.d_left = d_left;
     e->pend.d_right = d_right;
@@ -621,6 +629,32 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         pump();
     }
     uint64_t drained_to = e->pend.drained_to;
+    if (e->pend.lazy_repair && hipEventSynchronize(e->done[0]) == hipSuccess &&
+        e->h_err[kMaxChunks + 1] != nb * (uint32_t)channels) {
+        // Lazy repair (see launch_emit): the packer did not move every channel block -- a wave gave up, a bitstream did
+        // not fit its slot.  Now the repair kernels run: k_pack for the slots left behind, k_emit for what was never
+        // emitted, then the gather once more.  (One chunk; its k_offsets has run, the offsets are in place.)
+        const ChunkCtx cx = chunk_ctx(e, e->pend.d_left, e->pend.d_right, e->pend.frames, e->pend.layout, channels, chunks[0], 0);
+        LaunchSet ls = cx.set(e->pend.fuse_items, e->pend.emit_cap);
+        hipStream_t s = st[0];
+        hipError_t re = launch_emit(bind(ls), cx.w, e->pend.emit_dst, nullptr, nullptr, nullptr, s, true, e->ws.err_flag + kMaxChunks + 1,
+                                    nb * (uint32_t)channels, nullptr, e->ws.err_flag + kMaxChunks + 3, false);
+        GatherList g;
+        auto mapped = [](auto* host) -> decltype(host) {
+            void* d = nullptr;
+            return hipHostGetDevicePointer(&d, host, 0) == hipSuccess ? static_cast<decltype(host)>(d) : nullptr;
+        };
+        uint32_t *m_err = mapped(e->h_err), *m_emitted = mapped(e->h_emitted);
+        if (re == hipSuccess && m_err && m_emitted) {
+            g.add(cx.w.err_flag, &m_err[0], sizeof(uint32_t));
+            g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
+            g.add(e->ws.packed, m_emitted, (size_t)nb * channels * sizeof(uint32_t));
+            re = launch_gather(g, s);
+        }
+        if (re == hipSuccess) re = hipEventRecord(e->done[0], s);
+        if (re != hipSuccess) status = hip_fail(e, re, "repair launch");
+        e->timing.regrows += 0;  // (not a regrow; the counters below say what happened: moved_by_k_pack, packer_gave_up)
+    }
     for (size_t c = 0; c < chunks.size(); ++c) {
         const hipError_t he = hipEventSynchronize(e->done[c]);
         if (he != hipSuccess) {

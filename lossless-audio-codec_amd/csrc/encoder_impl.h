@@ -72,6 +72,7 @@ struct Knobs {
     uint32_t pipe_chunks = 0;      // LACX_PIPE_CHUNKS
     std::string pipe_split;        // LACX_PIPE_SPLIT
     uint32_t drain_fence = 0;      // LACX_DRAIN_FENCE
+    bool lazy_repair = true;       // LACX_NO_LAZY_REPAIR unset
     bool front_halves = true;      // LACX_NO_FRONT_HALVES unset: a one-chunk shard's front kernels in two block halves on two streams
     bool front_stream_split = false; // LACX_FRONT_STREAM: upload pipeline with the front kernels on a high-priority stream (experiment)
     uint32_t fanout_exchange = 0;  // LACX_FANOUT_EXCHANGE: 0 auto (RCCL where the devices are distinct), 1 host, 2 rccl
@@ -164,6 +165,10 @@ struct lacx_encoder {
         bool fused = false;
         bool drained = false;     // packer -> d_payload, copy engine -> h_payload (see h_range)
         uint32_t ranges = 0;
+        bool lazy_repair = false;  // k_pack / k_emit not enqueued: the gather kernel says whether they are needed
+        uint32_t fuse_items = 0;
+        uint64_t emit_cap = 0;
+        uint8_t* emit_dst = nullptr;
         bool front_split = false;  // upload pipeline: chunk c ran on stream 1 + c % 3
         uint32_t next_range = 0;  // copy-engine drain: first range not yet looked at, bytes already on their way
         uint64_t drained_to = 0;

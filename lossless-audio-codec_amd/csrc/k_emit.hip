@@ -435,7 +435,7 @@ int debug_read_offset_stamps(unsigned long long* out8) {  // (diagnostic builds 
 hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
                        hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted, const uint32_t* moved_total,
-                       uint32_t shard_items, hipEvent_t wait_before_pack, uint32_t* repacked) {
+                       uint32_t shard_items, hipEvent_t wait_before_pack, uint32_t* repacked, bool lazy_repair) {
     const hipError_t attr_err = ensure_kernel_attrs();
     if (attr_err != hipSuccess) return attr_err;
     const uint32_t nb = ls.br.total_blocks;
@@ -454,6 +454,7 @@ hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* 
         const hipError_t we = hipStreamWaitEvent(stream, wait_before_pack, 0);
         if (we != hipSuccess) return we;
     }
+    if (lazy_repair) return hipGetLastError();
     const uint32_t work = ls.total_items;
     if (skip_emitted && ws.slots) {
         hipLaunchKernelGGL(k_pack, dim3(work < (uint32_t)kPackGrid ? work : (uint32_t)kPackGrid), dim3(kPackThreads), 0, stream, ls.br, work,

@@ -139,11 +139,14 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
 // has; when they agree k_pack and k_emit have nothing to do and return at once (null: always look).
 // wait_before_pack: the packer's completion event; k_offsets does not depend on it and runs in front of the wait.
 // repacked (nullable): counts the channel blocks k_pack had to move.
+// lazy_repair: only k_offsets and the wait for the packer are enqueued; whether k_pack / k_emit have anything to do the
+// host sees from the packer's count of moved channel blocks (gathered with the rest) and enqueues them in the rare case
+// that they do -- on the common path two kernels and an event less between the end of the analysis and the host's wake-up.
 hipError_t launch_emit(const LaunchSet& ls, const DeviceWorkspace& ws, uint8_t* out,
                        const unsigned long long* base_ptr, hipEvent_t wait_before_offsets,
                        hipEvent_t offsets_done, hipStream_t stream, bool skip_emitted = true,
                        const uint32_t* moved_total = nullptr, uint32_t shard_items = 0,
-                       hipEvent_t wait_before_pack = nullptr, uint32_t* repacked = nullptr);
+                       hipEvent_t wait_before_pack = nullptr, uint32_t* repacked = nullptr, bool lazy_repair = false);
 
 // The streaming packer of the fused emit: runs beside the analysis kernels on its own stream and moves the staging
 // slots of the set's stream indices to their place in `out` as they are published.  counters: [0] error flags, [1] the
