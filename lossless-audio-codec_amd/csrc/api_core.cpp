@@ -569,6 +569,7 @@ void lacx_encoder_destroy(lacx_encoder* e) {
         if (e->h_totals) (void)hipHostFree(e->h_totals);
         if (e->h_err) (void)hipHostFree(e->h_err);
         if (e->h_emitted) (void)hipHostFree(e->h_emitted);
+        if (e->h_sizes) (void)hipHostFree(e->h_sizes);
         if (e->h_tspan) (void)hipHostFree(e->h_tspan);
         if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
         if (e->front_stream) (void)hipStreamDestroy(e->front_stream);

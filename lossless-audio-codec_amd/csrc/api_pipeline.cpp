@@ -484,10 +484,25 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         (void)cr;
         (void)prm;
         LaunchSet ls = cx.set(fuse_items, emit_cap);
-        HIP_TRY(e, launch_emit(bind(ls), w, emit_dst, prev_end, c ? e->copied[c - 1] : nullptr,
-                               e->copied[c], s, true, packer_counts ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
-                               nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr,
-                               e->ws.err_flag + kMaxChunks + 3, lazy), "emit launch");
+        if (lazy) {
+            // Not even k_offsets: the block table follows from the size records the analysis kernel published (the host
+            // adds them up), the repair kernels -- the only readers of the device-side offsets -- are enqueued on demand,
+            // k_offsets in front of them.  All that stands between the end of the analysis and the host is the packer's
+            // completion and one gather kernel.
+            if (nb * (uint32_t)channels > e->h_sizes_cap) {
+                if (e->h_sizes) (void)hipHostFree(e->h_sizes);
+                e->h_sizes = nullptr;
+                e->h_sizes_cap = 0;
+                HIP_TRY(e, hipHostMalloc((void**)&e->h_sizes, (size_t)nb * channels * sizeof(unsigned long long), 0), "hipHostMalloc(sizes)");
+                e->h_sizes_cap = nb * (uint32_t)channels;
+            }
+            HIP_TRY(e, hipStreamWaitEvent(s, e->pack_done, 0), "stream wait");
+        } else {
+            HIP_TRY(e, launch_emit(bind(ls), w, emit_dst, prev_end, c ? e->copied[c - 1] : nullptr,
+                                   e->copied[c], s, true, packer_counts ? e->ws.err_flag + kMaxChunks + 1 : nullptr,
+                                   nb * (uint32_t)channels, packer_counts ? e->pack_done : nullptr,
+                                   e->ws.err_flag + kMaxChunks + 3, false), "emit launch");
+        }
         e->pend.lazy_repair = lazy;
         prev_end = w.block_off + ck.count;
         HIP_TRY(e, hipEventRecord(e->ev[c][5], s), "event record");
@@ -503,8 +518,16 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         if (!m_bplans || !m_table || !m_err || !m_totals || !m_tspan || (fused && !m_emitted))
             return fail(e, LACX_E_RUNTIME, "hipHostGetDevicePointer failed");
         g.add(w.bplans, m_bplans + ck.first, (size_t)ck.count * sizeof(BlockPlan));
-        g.add(w.table, m_table + (size_t)ck.first * 2, (size_t)ck.count * 2 * sizeof(uint32_t));
-        g.add(w.block_off + ck.count, &m_totals[c], sizeof(unsigned long long));
+        if (lazy) {
+            unsigned long long* m_sizes = mapped(e->h_sizes);
+            if (!m_sizes) return fail(e, LACX_E_RUNTIME, "hipHostGetDevicePointer failed");
+            g.add(e->ws.size_rec, m_sizes, (size_t)nb * channels * sizeof(unsigned long long));
+            // the "all kernels done" word: any record (its valid bit makes it non-zero); the host puts the total there
+            g.add(e->ws.size_rec, &m_totals[c], sizeof(unsigned long long));
+        } else {
+            g.add(w.table, m_table + (size_t)ck.first * 2, (size_t)ck.count * 2 * sizeof(uint32_t));
+            g.add(w.block_off + ck.count, &m_totals[c], sizeof(unsigned long long));
+        }
         g.add(w.err_flag, &m_err[c], sizeof(uint32_t));
         // the packer's error flags, moved count, waves that gave up, and k_pack's repacked count
         if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
@@ -629,8 +652,27 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
         pump();
     }
     uint64_t drained_to = e->pend.drained_to;
-    if (e->pend.lazy_repair && hipEventSynchronize(e->done[0]) == hipSuccess &&
-        e->h_err[kMaxChunks + 1] != nb * (uint32_t)channels) {
+    if (e->pend.lazy_repair && hipEventSynchronize(e->done[0]) == hipSuccess) {
+        // the block table and the payload's size from the size records (k_offsets never ran on this path)
+        unsigned long long total = 0;
+        bool complete = true;
+        for (uint32_t b = 0; b < nb; ++b) {
+            unsigned long long bytes = 0;
+            for (int ch = 0; ch < channels; ++ch) {
+                const unsigned long long rec = e->h_sizes[(size_t)b * channels + ch];
+                complete = complete && (rec >> 62) == 1ull;  // (kRecValid)
+                bytes += rec & ((1ull << 60) - 1ull);
+            }
+            e->h_table[2 * (size_t)b] = e->h_bplans[b].frames;
+            e->h_table[2 * (size_t)b + 1] = (uint32_t)bytes;
+            total += bytes;
+        }
+        e->h_totals[0] = total;
+        bool any_invalid = false;
+        for (uint32_t b = 0; b < nb; ++b) any_invalid = any_invalid || e->h_bplans[b].invalid;
+        if (!complete && !any_invalid) status = fail(e, LACX_E_RUNTIME, "a channel block's size record is missing (internal error)");
+    }
+    if (status == LACX_OK && e->pend.lazy_repair && e->h_err[kMaxChunks + 1] != nb * (uint32_t)channels) {
         // Lazy repair (see launch_emit): the packer did not move every channel block -- a wave gave up, a bitstream did
         // not fit its slot.  Now the repair kernels run: k_pack for the slots left behind, k_emit for what was never
         // emitted, then the gather once more.  (One chunk; its k_offsets has run, the offsets are in place.)
@@ -645,7 +687,11 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
             return hipHostGetDevicePointer(&d, host, 0) == hipSuccess ? static_cast<decltype(host)>(d) : nullptr;
         };
         uint32_t *m_err = mapped(e->h_err), *m_emitted = mapped(e->h_emitted);
-        if (re == hipSuccess && m_err && m_emitted) {
+        uint32_t* m_table = mapped(e->h_table);
+        unsigned long long* m_totals = mapped(e->h_totals);
+        if (re == hipSuccess && m_err && m_emitted && m_table && m_totals) {
+            g.add(cx.w.table, m_table, (size_t)nb * 2 * sizeof(uint32_t));
+            g.add(cx.w.block_off + nb, &m_totals[0], sizeof(unsigned long long));
             g.add(cx.w.err_flag, &m_err[0], sizeof(uint32_t));
             g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
             g.add(e->ws.packed, m_emitted, (size_t)nb * channels * sizeof(uint32_t));

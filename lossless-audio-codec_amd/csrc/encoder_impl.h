@@ -195,6 +195,8 @@ struct lacx_encoder {
     uint32_t* h_table = nullptr;   // pinned, [blocks][2]
     unsigned long long* h_totals = nullptr;  // pinned, per chunk payload bytes
     uint32_t* h_err = nullptr;     // pinned, per chunk
+    unsigned long long* h_sizes = nullptr;  // pinned copy of the size records (lazy repair: the host builds the block table from them)
+    uint32_t h_sizes_cap = 0;
     uint32_t* h_emitted = nullptr; // pinned copy of ws.emitted (statistics of the fused emit)
     uint32_t h_emitted_cap = 0;
     unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: ~first-start / last-end device clock of k_analyze<16,1024>
