@@ -153,6 +153,7 @@ class StepLog:
     def __init__(self):
         import gc
         self.rows = {k: [] for k in self.KEYS}
+        self._raw = []
         self._gc_t0 = None
         self._gc_ms = 0.0
         self._gc = gc
@@ -187,27 +188,35 @@ class StepLog:
         self._t = time.perf_counter()
 
     def end(self, timings):
-        """timings: the lacx_timing of every encoder call the step made (summed where that makes sense, max otherwise)."""
+        """timings: the lacx_timing of every encoder call the step made.  Only the clock and the references are taken
+        here (the step is inside a timed region); the fields are worked out in summary()."""
+        now = time.perf_counter()
+        self._raw.append((now - self._t, self._gc_ms, timings))
+
+    def _digest(self):
         r = self.rows
-        r["wall_ms"].append(round((time.perf_counter() - self._t) * 1e3, 3))
-        r["gc_ms"].append(round(self._gc_ms, 3))
-        add = lambda f: round(sum(getattr(t, f) for t in timings), 3)  # noqa: E731
-        mx = lambda f: round(max(getattr(t, f) for t in timings), 3)  # noqa: E731
-        r["lib_total_ms"].append(mx("total_ms"))
-        r["analysis_ms"].append(add("analysis_ms"))
-        r["full_ms"].append(add("full_ms"))
-        r["enqueue_ms"].append(mx("enqueue_ms"))
-        r["kernels_done_ms"].append(mx("kernels_done_ms"))
-        r["drain_first_ms"].append(mx("drain_first_ms"))
-        r["drain_last_ms"].append(mx("drain_last_ms"))
-        r["poll_gap_max_ms"].append(mx("poll_gap_max_ms"))
-        r["drain_copies"].append(int(sum(t.drain_copies for t in timings)))
-        r["emit_direct"].append(int(sum(t.emit_direct for t in timings)))
-        r["moved_by_k_pack"].append(int(sum(t.moved_by_k_pack for t in timings)))
-        r["packer_gave_up"].append(int(sum(t.packer_gave_up for t in timings)))
+        for wall, gc_ms, timings in self._raw:
+            r["wall_ms"].append(round(wall * 1e3, 3))
+            r["gc_ms"].append(round(gc_ms, 3))
+            add = lambda f: round(sum(getattr(t, f) for t in timings), 3)  # noqa: E731
+            mx = lambda f: round(max(getattr(t, f) for t in timings), 3)  # noqa: E731
+            r["lib_total_ms"].append(mx("total_ms"))
+            r["analysis_ms"].append(add("analysis_ms"))
+            r["full_ms"].append(add("full_ms"))
+            r["enqueue_ms"].append(mx("enqueue_ms"))
+            r["kernels_done_ms"].append(mx("kernels_done_ms"))
+            r["drain_first_ms"].append(mx("drain_first_ms"))
+            r["drain_last_ms"].append(mx("drain_last_ms"))
+            r["poll_gap_max_ms"].append(mx("poll_gap_max_ms"))
+            r["drain_copies"].append(int(sum(t.drain_copies for t in timings)))
+            r["emit_direct"].append(int(sum(t.emit_direct for t in timings)))
+            r["moved_by_k_pack"].append(int(sum(t.moved_by_k_pack for t in timings)))
+            r["packer_gave_up"].append(int(sum(t.packer_gave_up for t in timings)))
+        self._raw = []
 
     def summary(self):
         import statistics
+        self._digest()
         out = {}
         for k, v in self.rows.items():
             if not v:
@@ -910,6 +919,7 @@ def worker(args) -> int:
                     log.end(tms)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t1) / steps
+            log._digest()
             each = log.rows["wall_ms"]
             ok = True
             for j, (pay, tab) in zip(jobs, res):
