@@ -233,7 +233,7 @@ struct NoEmitOut {};
 
 template <class G>
 struct Smem {
-    uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate (transposed); bits 30/31 = micro flags; +4: peek_u looks up to 3 samples past the slot
+    uint32_t u[G::MAXN + 4];  // zigzag residual of the current candidate (transposed), always plain (the micro-window flags live in tabZM / tabLM); +4: peek_u looks up to 3 samples past the slot
     union XP {
         int32_t x[G::MAXN];  // staged samples (transposed), zero beyond n
         PartMem<G> part;
@@ -242,7 +242,8 @@ struct Smem {
     uint64_t tabP[G::T + 1];  // in: chunk sums; after scan: exclusive prefix, [T] = total
     int32_t tabNZ[G::T + 1];  // in: last non-zero index in chunk (-1); after scan: exclusive prefix max
     uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
-    uint16_t tabZM[G::T];     // phase A: bit i = sample i of the chunk has the "zero quotient" micro flag (phase_b_quick)
+    uint16_t tabZM[G::T];     // phase A: bit i = sample i of the chunk has the "zero quotient" micro flag (q == 0)
+    uint16_t tabLM[G::T];     // phase A: bit i = sample i of the chunk has the "large quotient" micro flag (q > 3)
     uint16_t tabUZ[G::T + 2]; // phase A: bit i = sample i of the chunk is zero ([T]: stays 0, "not a zero" past the slot)
     uint16_t bqueue[G::T];    // chunks whose adaptive costs need the walk (phase B), packed over the lanes of the waves
     uint32_t bqcount;
@@ -804,8 +805,10 @@ LACX_HD uint32_t pick_static_k(const uint64_t* A, uint32_t m, uint64_t* bits) {
     return best_k;
 }
 
-// Phase A: unbiased k after every sample -> micro-window flags into bits 30/31 of u (ref rice.hpp:68-80),
-// and the chunk's packed flag counts.
+// Phase A: unbiased k after every sample -> the micro-window flags of every sample (ref rice.hpp:68-80) as two 16-bit
+// masks per chunk (tabZM: quotient == 0, tabLM: quotient > 3) and the chunk's packed flag counts.  u itself is not
+// touched (round 4: the flags used to go into bits 30 / 31 of u -- sixteen LDS writes per thread and candidate, a mask
+// on every later read and a pass over the whole residual to strip them before the partition search).
 template <class G, bool NARROW, class M>
 LACX_HD void phase_a(Thread<G>& th, M& sh) {
     uint64_t P = sh.tabP[th.tid];
@@ -814,6 +817,7 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
     uint32_t zm = 0;  // bit i: sample i of the chunk is zero
     uint32_t mn = 0xFFFFFFFFu;
     uint32_t fzm = 0;  // bit i: sample i has the zero-quotient flag
+    uint32_t flm = 0;  // bit i: sample i has the large-quotient flag
     for (int i = 0; i < th.cnt; ++i) {
         const uint32_t u = sh.u[i * G::T + th.tid];
         mn = u < mn ? u : mn;
@@ -822,16 +826,15 @@ LACX_HD void phase_a(Thread<G>& th, M& sh) {
         const uint32_t km = kmean_t<NARROW>(P, c);
         const uint32_t q = u >> km;  // km <= 31 and u < 2^30
         const uint32_t fl = q > 3u, fz = q == 0u;
-        sh.u[i * G::T + th.tid] = u | (fl << 30) | (fz << 31);
         cnt += fl + (fz << 16);
         zm |= (u == 0u ? 1u : 0u) << i;
         fzm |= fz << i;
+        flm |= fl << i;
     }
     sh.tabF[th.tid] = cnt;
-    if constexpr (requires { sh.tabZM[0]; }) {
-        sh.tabZM[th.tid] = (uint16_t)fzm;
-        sh.tabUZ[th.tid] = (uint16_t)zm;
-    }
+    sh.tabZM[th.tid] = (uint16_t)fzm;
+    sh.tabLM[th.tid] = (uint16_t)flm;
+    if constexpr (requires { sh.tabUZ[0]; }) sh.tabUZ[th.tid] = (uint16_t)zm;
     th.umin = mn;
     th.zmask = zm;
     // Zero-run mode can only matter when some run of >= 4 zeros exists (ref block/encoder.cpp:224-247 sets
@@ -883,21 +886,23 @@ LACX_HD ChunkCosts phase_b_span(const Smem<G>& sh, uint32_t n, int t, int i0, in
     // packed flag counts over the 96 samples before the chunk = its W96 predecessors' chunk counts (the window
     // starts on a chunk boundary); kept up to date sample by sample below
     uint32_t D = window_flags<G>(sh.tabF, t);
-    const uint32_t m256 = (STEADY || t >= G::W256) ? 0x3FFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
-    const uint32_t m96 = (STEADY || t >= G::W96) ? 0xFFFFFFFFu : 0u;
+    const uint32_t m256 = (STEADY || t >= G::W256) ? 0xFFFFFFFFu : 0u;   // window taps exist from chunk W256 / W96 on
     const int t256 = (STEADY || t >= G::W256) ? t - G::W256 : t;
     const int t96 = (STEADY || t >= G::W96) ? t - G::W96 : t;
+    // micro-window flags of this chunk's samples (they enter the 96-window) and of the chunk 96 samples back (they leave
+    // it): large-quotient flag of sample i in bit i, zero-quotient flag in bit 16 + i -- the packed counts' layout
+    const uint32_t fin = (uint32_t)sh.tabLM[t] | ((uint32_t)sh.tabZM[t] << 16);
+    const uint32_t fout = (STEADY || t >= G::W96) ? ((uint32_t)sh.tabLM[t96] | ((uint32_t)sh.tabZM[t96] << 16)) : 0u;
     uint32_t c = (uint32_t)a;
     int32_t f = a - 1 - sh.tabNZ[t];  // zeros ending just before the chunk
     // carry the sums over the samples before the span (none when the span opens the chunk)
     for (int j = 0; j < i0; ++j) {
-        const uint32_t w = sh.u[j * G::T + t], w96 = sh.u[j * G::T + t96] & m96;
-        const uint32_t u = w & 0x3FFFFFFFu;
+        const uint32_t u = sh.u[j * G::T + t];
         P += u;
         ++c;
         W += sh.u[j * G::T + t256] & m256;
-        D += ((w >> 30) & 1u) + ((w >> 31) << 16);
-        D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
+        D += (fin >> j) & 0x00010001u;
+        D -= (fout >> j) & 0x00010001u;
         f = (f + 1) & (int32_t)(0u - flag01(u == 0u));
     }
     // k in force for the first sample of the span: the value returned after the sample before it
@@ -915,17 +920,16 @@ LACX_HD ChunkCosts phase_b_span(const Smem<G>& sh, uint32_t n, int t, int i0, in
         n2 = peek_u<G>(sh, (uint32_t)(a + i0) + 2u, n);
         n3 = peek_u<G>(sh, (uint32_t)(a + i0) + 3u, n);
     }
-    // the window taps of the current trip are fetched one trip ahead (their latency hides behind the trip's arithmetic)
-    uint32_t tap256 = sh.u[ifirst * G::T + t256], tap96 = sh.u[ifirst * G::T + t96];
+    // the window tap of the current trip is fetched one trip ahead (its latency hides behind the trip's arithmetic)
+    uint32_t tap256 = sh.u[ifirst * G::T + t256];
     const int last = TRIPS > 0 ? i0 + TRIPS : i1;
 #pragma nounroll  // one sample per trip: the 16-fold body does not fit the register budget
     for (int i = i0; i < last; ++i) {
-        const uint32_t cur256 = tap256, cur96 = tap96;
+        const uint32_t cur256 = tap256;
         const int inext = (i + 1) & (G::CH - 1);
         const uint32_t wnext = sh.u[inext * G::T + t];
         tap256 = sh.u[inext * G::T + t256];
-        tap96 = sh.u[inext * G::T + t96];
-        const uint32_t u = w0 & 0x3FFFFFFFu;
+        const uint32_t u = w0;
         const uint32_t rc = (u >> kin) + 1u + kin;  // kin <= 31 (biased_k clamps) and u < 2^30: no k >= 31 special case
         rice += rc;
         bin += 2u + ((u <= 4u) ? (u < 1u ? u : 1u) : rc);  // 2 for a zero, 3 for 1..4, else 2 + the Rice code
@@ -945,9 +949,8 @@ LACX_HD ChunkCosts phase_b_span(const Smem<G>& sh, uint32_t n, int t, int i0, in
         P += u;
         ++c;
         W += cur256 & m256;
-        const uint32_t w96 = cur96 & m96;
-        D += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);       // sample j enters the window ...
-        D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);     // ... sample j-96 leaves it
+        D += (fin >> i) & 0x00010001u;    // sample j enters the window ...
+        D -= (fout >> i) & 0x00010001u;   // ... sample j-96 leaves it
         kin = biased_k<NARROW, STEADY>(kmean_t<NARROW>(P, c), P, W, D, c);
         // slide the lookahead window
         w0 = wnext;

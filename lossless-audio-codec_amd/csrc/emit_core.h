@@ -17,7 +17,7 @@ namespace lacx {
 
 template <class G>
 struct EmitMem {
-    uint32_t u[G::MAXN + 4];  // zigzag residual (transposed); bits 30/31 = micro flags during the stateful walk; +4: lookahead pad
+    uint32_t u[G::MAXN + 4];  // zigzag residual (transposed), plain; +4: lookahead pad
     union XP {
         int32_t x[G::MAXN];  // staged samples until the residual is formed
         EmitOut<G> o;        // output tile + Rice parameter per sample (analyze_core.h)
@@ -26,6 +26,8 @@ struct EmitMem {
     int32_t tabNZ[G::T + 1];  // last non-zero index -> exclusive prefix max
     int32_t tabNX[G::T + 1];  // first non-zero index -> exclusive suffix min (n if none)
     uint32_t tabF[G::T + 1];  // packed micro-window flag counts of every chunk (phase A)
+    uint16_t tabZM[G::T];     // ... and the flags themselves, sample by sample (zero quotient / large quotient)
+    uint16_t tabLM[G::T];
     uint64_t wtotP[16];
     int32_t wtotZ[16];
     uint32_t wtotF[16];
@@ -212,8 +214,11 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, M& sh, const BitTile* tile_in,
     uint64_t Pseg = 0, W = 0;
     uint32_t D = 0, kin = k0;  // D: packed flag counts over the last 96 samples
     const bool stateful = (p == 0);
-    const uint32_t m256 = (t >= G::W256) ? 0x3FFFFFFFu : 0u, m96 = (t >= G::W96) ? 0xFFFFFFFFu : 0u;
+    const uint32_t m256 = (t >= G::W256) ? 0xFFFFFFFFu : 0u;
     const int t256 = (t >= G::W256) ? t - G::W256 : t, t96 = (t >= G::W96) ? t - G::W96 : t;
+    // micro-window flags entering / leaving the 96-window (stateful walk only; layout of the packed counts, see phase_b_span)
+    const uint32_t fin = (pass1 && p == 0u) ? ((uint32_t)sh.tabLM[t] | ((uint32_t)sh.tabZM[t] << 16)) : 0u;
+    const uint32_t fout = (pass1 && p == 0u && t >= G::W96) ? ((uint32_t)sh.tabLM[t96] | ((uint32_t)sh.tabZM[t96] << 16)) : 0u;
     uint32_t c = (uint32_t)th.a;
     if (pass1) {
         if (stateful) {
@@ -322,9 +327,8 @@ LACX_HD uint64_t emit_walk_t(const Thread<G>& th, M& sh, const BitTile* tile_in,
             ++c;
             if (stateful) {
                 W += sh.u[i * G::T + t256] & m256;
-                const uint32_t w96 = sh.u[i * G::T + t96] & m96;
-                D += ((w0 >> 30) & 1u) + ((w0 >> 31) << 16);
-                D -= ((w96 >> 30) & 1u) + ((w96 >> 31) << 16);
+                D += (fin >> i) & 0x00010001u;
+                D -= (fout >> i) & 0x00010001u;
                 kin = biased_k<NARROW>(kmean_t<NARROW>(P, c), P, W, D, c);
             } else {
                 kin = kmean_t<NARROW>(P - Pseg, j + 1u - s);

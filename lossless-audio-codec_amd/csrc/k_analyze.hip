@@ -488,11 +488,9 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         if (tid <= G::MAXP) pm.pbits[tid] = 0;
     };
     if (best == pending && !LACX_HOOK(prm, 16384u)) {
-        // The winner is the candidate evaluated last (usually the only one): its residual is still in sh.u, with the
-        // micro-window flags of phase A in bits 30/31, its prefix sums in tabP / tabNZ, its plane counts in th.cs.
-        // Strip the flags; nobody reads the staged samples any more (the last barrier of the search is behind us).
-#pragma unroll
-        for (int i = 0; i < G::CH; ++i) sh.u[i * G::T + tid] &= 0x3FFFFFFFu;
+        // The winner is the candidate evaluated last (usually the only one): its residual is still in sh.u (plain: the
+        // micro-window flags of phase A live in their own tables), its prefix sums in tabP / tabNZ, its plane counts in
+        // th.cs.  Nobody reads the staged samples any more (the last barrier of the search is behind us).
         clear_partition_scratch();
         slot_sync<G>();
     } else {
