@@ -460,6 +460,14 @@ def worker(args) -> int:
             d_right = torch.from_numpy(right).cuda()
         torch.cuda.synchronize()
 
+        # the exchange of the shard sizes: buffers made once, outside the timed loop (a fresh tensor per step and rank is a
+        # handful of allocations and fill kernels on every GPU)
+        xmine = xall = xhost = None
+        if world > 1:
+            xhost = torch.zeros(2, dtype=torch.int64).pin_memory() if xdev == "cuda" else torch.zeros(2, dtype=torch.int64)
+            xmine = torch.zeros(2, dtype=torch.int64, device=xdev)
+            xall = [torch.zeros(2, dtype=torch.int64, device=xdev) for _ in range(world)]
+
         def step():
             if args.analysis_only:
                 enc.analyze_device(d_left.data_ptr(), d_right.data_ptr(), frames, stream)
@@ -472,9 +480,10 @@ def worker(args) -> int:
                                                               stream)
             if world > 1:
                 # the block table is already on the host: sum it there, exchange two integers per rank
-                mine = torch.tensor([int(table[:, 1].sum(dtype=np.int64)), table.shape[0]], dtype=torch.int64, device=xdev)
-                allv = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allv, mine)  # per-shard payload bytes + block counts -> byte offsets
+                xhost[0] = int(table[:, 1].sum(dtype=np.int64))
+                xhost[1] = table.shape[0]
+                xmine.copy_(xhost, non_blocking=True)
+                dist.all_gather(xall, xmine)  # per-shard payload bytes + block counts -> byte offsets
             return payload, table
 
         inflight = args.inflight if (interleaved and world == 1) else 1
