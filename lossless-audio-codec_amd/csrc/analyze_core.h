@@ -427,13 +427,20 @@ LACX_HD void load_chunk(const SlotSrc& src, int64_t first, int cnt, int64_t last
     }
 }
 
+// Returns the OR of the chunk's samples (zero: the chunk is silent).
 template <class G, class M>
-LACX_HD void stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
+LACX_HD uint32_t stage_samples(const Thread<G>& th, M& sh, const SlotSrc& src, int64_t start) {
     int32_t v[G::CH];
     load_chunk<G::CH>(src, start + th.a, th.cnt, start + (int64_t)th.n - 1, v);
     int32_t* col = &sh.xp.x[th.tid];
+    uint32_t any = 0;
 #pragma unroll
-    for (int i = 0; i < G::CH; ++i) col[i * G::T] = (i < th.cnt) ? v[i] : 0;
+    for (int i = 0; i < G::CH; ++i) {
+        const int32_t x = (i < th.cnt) ? v[i] : 0;
+        col[i * G::T] = x;
+        any |= (uint32_t)x;
+    }
+    return any;
 }
 
 // bit-sliced add of two W-bit counters held as W words (bit b of word l = bit l of the count of plane b)

@@ -217,7 +217,12 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 #endif
     Thread<G> th;
     thread_init(th, n, tid);
-    stage_samples(th, sh, src, start);
+    const uint32_t chunk_bits = stage_samples(th, sh, src, start);
+    // (digital silence: every wave says whether it saw a non-zero sample; wtotF is free until the first scan)
+    {
+        const bool wave_silent = __ballot(chunk_bits != 0u) == 0ull;
+        if ((tid & 63) == 0) sh.wtotF[tid >> 6] = wave_silent ? 0u : 1u;
+    }
     for (int i = tid; i < (int)(sizeof(LpcSet) / 2); i += G::T)
         reinterpret_cast<uint16_t*>(&sh.lpc)[i] = reinterpret_cast<const uint16_t*>(lpc_slot)[i];
     if (tid < 32) {
@@ -292,6 +297,17 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
             reduce_pair(10, bl[4], false, bl[4]);
         }
     };
+    // A slot of nothing but zeros (digital silence) needs no bounds: every candidate's residual is the same zeros, so every
+    // cost is the same and the lowest index wins (ref block/encoder.cpp:352-359 keeps the first strictly smallest cost):
+    // candidate 0 is costed exactly, nothing else is looked at.
+    bool silent = true;
+#pragma unroll
+    for (int w = 0; w < G::T / 64; ++w) silent = silent && sh.wtotF[w] == 0u;  // (uniform)
+    if (silent) {
+        STAMP(2);
+        slot_sync<G>();  // (every wave has read the flags before the scans reuse wtotF)
+        if (tid <= 10) sh.cand_key[tid] = tid == 0 ? 0ull : ~0ull;
+    } else {
 #if defined(LACX_STAMPS) && LACX_STAMPS == 3
     {   // diagnostic: the same pass (the same code) twice in a row -- the second trip finds it in the instruction cache
         uint32_t trips = 2;
@@ -313,6 +329,7 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         sh.cand_key[tid] = avail ? ((candidate_lower_bound(sh.lbacc[tid][0], sh.lbacc[tid][1], sh.lbacc[tid][2], n, prm.zero_run) << 4) | (uint64_t)tid)
                                  : ~0ull;
     }
+    }  // (not silent)
     STAMP(5);
 
     // ---- pass 2: exact costs, most promising candidate first ----------------------------------------------------------
