@@ -117,6 +117,9 @@ typedef struct lacx_timing {
     double poll_gap_max_ms;   /* longest interval between two looks at the progress words (a descheduled or busy host thread) */
     double kernels_done_ms;   /* the host saw the last kernel's completion word */
     double enqueue_ms;        /* everything enqueued (the call's launch phase) */
+    uint32_t silent_copies;   /* channel blocks of nothing but zeros that were copies of the call's first one (plan and
+                                 bitstream are the same for every such block of the same length) */
+    uint32_t reserved0;
 } lacx_timing;
 
 int lacx_encoder_create(const lacx_config* cfg, lacx_encoder** out);

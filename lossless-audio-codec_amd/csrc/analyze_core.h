@@ -272,6 +272,7 @@ struct Smem {
     uint32_t ptype, order, p, parts, cand, header_bits, payload_bytes;
     uint32_t err;
     uint32_t plan_any_zr;  // finalize_plan: some partition of the plan uses zero-run mode
+    uint32_t tmpl_state, tmpl_pad[3];  // silent slots: the state word of the launch's SilentTemplate as thread 0 read it
 };
 
 template <class G>

@@ -38,6 +38,7 @@ Knobs read_knobs() {
     }
     k.front_halves = !set("LACX_NO_FRONT_HALVES");
     k.lazy_repair = !set("LACX_NO_LAZY_REPAIR");
+    k.silent_template = !set("LACX_NO_SILENT_TEMPLATE");
     k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
     k.pinned_cap_bytes = num("LACX_PINNED_CAP_BYTES");
     k.debug_skip = (uint32_t)num("LACX_DEBUG_SKIP");
@@ -132,7 +133,7 @@ int ensure_device(lacx_encoder* e) {
     HIP_TRY(e, hipEventCreateWithFlags(&e->prologue, hipEventDisableTiming), "hipEventCreate");
     for (auto& ev : e->aux_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
     HIP_TRY(e, hipHostMalloc((void**)&e->h_totals, sizeof(unsigned long long) * kMaxChunks, 0), "hipHostMalloc");
-    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 4), 0), "hipHostMalloc");
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_err, sizeof(uint32_t) * (kMaxChunks + 8), 0), "hipHostMalloc");
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -173,6 +174,7 @@ void free_workspace(lacx_encoder* e) {
     e->zero_region = nullptr;
     e->d_tspan = nullptr;
     e->d_work_ctr = nullptr;
+    e->d_silent = nullptr;
     e->ws = DeviceWorkspace{};
     e->ws_blocks = 0;
 }
@@ -200,9 +202,10 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             const size_t items = (size_t)nblocks * 2 + 4;
             const size_t ranges = items / kPackerRangeItems + 2;  // packer progress (copy-engine drain)
             const size_t bytes = items * (2 * sizeof(unsigned long long) + 2 * sizeof(uint32_t)) +
-                                 sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 4) +
+                                 sizeof(unsigned long long) * 2 * kMaxChunks + sizeof(uint32_t) * (kMaxChunks + 8) +
                                  ranges * (sizeof(unsigned long long) + sizeof(uint32_t)) + 16 +
-                                 sizeof(uint32_t) * 8 * (kMaxChunks + 1);  // work counters of the persistent analysis
+                                 sizeof(uint32_t) * 8 * (kMaxChunks + 1) +  // work counters of the persistent analysis
+                                 16 + sizeof(SilentTemplate);
             e->zero_bytes = (bytes + 15) & ~(size_t)15;
             HIP_TRY(e, hipMalloc((void**)&e->zero_region, e->zero_bytes), "hipMalloc(zeroed region)");
             uint8_t* p = e->zero_region;
@@ -217,7 +220,7 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             e->ws.packed = reinterpret_cast<uint32_t*>(p);
             p += items * sizeof(uint32_t);
             e->ws.err_flag = reinterpret_cast<uint32_t*>(p);
-            p += sizeof(uint32_t) * (kMaxChunks + 4);
+            p += sizeof(uint32_t) * (kMaxChunks + 8);
             p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 7) & ~(uintptr_t)7);
             e->d_range_end = reinterpret_cast<unsigned long long*>(p);
             p += ranges * sizeof(unsigned long long);
@@ -225,6 +228,9 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
             p += ranges * sizeof(uint32_t);
             p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 3) & ~(uintptr_t)3);
             e->d_work_ctr = reinterpret_cast<uint32_t*>(p);
+            p += sizeof(uint32_t) * 8 * (kMaxChunks + 1);
+            p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+            e->d_silent = reinterpret_cast<SilentTemplate*>(p);
         }
         e->ws_blocks = nblocks;
     }

@@ -315,6 +315,7 @@ void merge_timing(lacx_encoder* e, uint32_t G, clk::time_point t0) {
         t.regrows += c.regrows;
         t.emit_direct += c.emit_direct;
         t.moved_by_k_pack += c.moved_by_k_pack;
+        t.silent_copies += c.silent_copies;
         t.packer_gave_up += c.packer_gave_up;
     }
     t.total_ms = ms_since(t0);

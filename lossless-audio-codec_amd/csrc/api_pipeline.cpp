@@ -394,6 +394,8 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
             fa.err_flag = w.err_flag;
             fa.size_rec = e->ws.size_rec;
             fa.ready_rec = e->ws.ready_rec;
+            fa.silent = e->knobs.silent_template ? e->d_silent : nullptr;
+            fa.silent_copies = e->ws.err_flag + kMaxChunks + 4;
         }
         if (hs) {
             // this chunk's PCM is being copied by the uploader thread: wait (on the host) until its copy has been issued and
@@ -530,7 +532,7 @@ int encode_device_begin_impl(lacx_encoder* e, const int32_t* d_left, const int32
         }
         g.add(w.err_flag, &m_err[c], sizeof(uint32_t));
         // the packer's error flags, moved count, waves that gave up, and k_pack's repacked count
-        if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
+        if (c + 1 == chunks.size()) g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 5 * sizeof(uint32_t));
         if (fused)
             g.add(e->ws.packed + (size_t)ck.first * channels, m_emitted + (size_t)ck.first * channels,
                   (size_t)ck.count * channels * sizeof(uint32_t));
@@ -693,7 +695,7 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
             g.add(cx.w.table, m_table, (size_t)nb * 2 * sizeof(uint32_t));
             g.add(cx.w.block_off + nb, &m_totals[0], sizeof(unsigned long long));
             g.add(cx.w.err_flag, &m_err[0], sizeof(uint32_t));
-            g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
+            g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 5 * sizeof(uint32_t));
             g.add(e->ws.packed, m_emitted, (size_t)nb * channels * sizeof(uint32_t));
             re = launch_gather(g, s);
         }
@@ -787,11 +789,12 @@ int encode_device_end(lacx_encoder* e, uint64_t* payload_size) {
     }
     e->timing.full_launches = (uint32_t)chunks.size();
     e->timing.full_slots = (uint64_t)nb * (channels == 2 ? 2u : 1u);
-    e->timing.emit_direct = e->timing.moved_by_k_pack = e->timing.packer_gave_up = 0;
+    e->timing.emit_direct = e->timing.moved_by_k_pack = e->timing.packer_gave_up = e->timing.silent_copies = 0;
     if (e->pend.fused) {
         for (size_t i = 0; i < (size_t)nb * (size_t)channels; ++i) e->timing.emit_direct += e->h_emitted[i] == 1u;
         e->timing.packer_gave_up = e->h_err[kMaxChunks + 2];
         e->timing.moved_by_k_pack = e->h_err[kMaxChunks + 3];
+        e->timing.silent_copies = e->h_err[kMaxChunks + 4];
     }
     e->timing.full_exec_ms = 0;
     for (size_t c = 0; c < chunks.size(); ++c) {
@@ -956,6 +959,8 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     fa.err_flag = w.err_flag;
     fa.size_rec = e->ws.size_rec;
     fa.ready_rec = e->ws.ready_rec;
+    fa.silent = e->knobs.silent_template ? e->d_silent : nullptr;
+    fa.silent_copies = e->ws.err_flag + kMaxChunks + 4;
     auto run = [&]() -> int {
         HIP_TRY(e, launch_analysis(ls, w, s, e->ev[0], &fa, nullptr, e->knobs.tune), "kernel launch");
         const bool packer = e->knobs.packer;
@@ -979,7 +984,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
         g.add(w.bplans, m_bplans, (size_t)nb * sizeof(BlockPlan));
         g.add(w.table, m_table, (size_t)nb * 2 * sizeof(uint32_t));
         g.add(w.err_flag, &m_err[0], sizeof(uint32_t));
-        g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 4 * sizeof(uint32_t));
+        g.add(e->ws.err_flag + kMaxChunks, &m_err[kMaxChunks], 5 * sizeof(uint32_t));
         g.add(e->ws.packed, m_emitted, (size_t)nitems * sizeof(uint32_t));
         g.add(w.t_first, &m_tspan[0], sizeof(unsigned long long));
         g.add(w.t_last, &m_tspan[kMaxChunks], sizeof(unsigned long long));
@@ -1036,6 +1041,7 @@ int encode_batch(lacx_encoder* e, const lacx_batch_item* items, uint32_t n, hipS
     for (uint32_t i = 0; i < nitems; ++i) e->timing.emit_direct += e->h_emitted[i] == 1u;
     e->timing.packer_gave_up = e->h_err[kMaxChunks + 2];
     e->timing.moved_by_k_pack = e->h_err[kMaxChunks + 3];
+    e->timing.silent_copies = e->h_err[kMaxChunks + 4];
     {
         const unsigned long long a = ~e->h_tspan[0], b = e->h_tspan[kMaxChunks];
         e->timing.full_exec_ms = b > a ? (double)(b - a) * 1e-5 : 0.0;

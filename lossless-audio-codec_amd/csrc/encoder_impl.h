@@ -73,6 +73,7 @@ struct Knobs {
     std::string pipe_split;        // LACX_PIPE_SPLIT
     uint32_t drain_fence = 0;      // LACX_DRAIN_FENCE
     bool lazy_repair = true;       // LACX_NO_LAZY_REPAIR unset
+    bool silent_template = true;   // LACX_NO_SILENT_TEMPLATE unset: silent slots after the first are copies (kernels.h)
     bool front_halves = true;      // LACX_NO_FRONT_HALVES unset: a one-chunk shard's front kernels in two block halves on two streams
     bool front_stream_split = false; // LACX_FRONT_STREAM: upload pipeline with the front kernels on a high-priority stream (experiment)
     uint32_t fanout_exchange = 0;  // LACX_FANOUT_EXCHANGE: 0 auto (RCCL where the devices are distinct), 1 host, 2 rccl
@@ -200,6 +201,7 @@ struct lacx_encoder {
     uint32_t* h_emitted = nullptr; // pinned copy of ws.emitted (statistics of the fused emit)
     uint32_t h_emitted_cap = 0;
     unsigned long long* d_tspan = nullptr;  // [2][kMaxChunks]: ~first-start / last-end device clock of k_analyze<16,1024>
+    SilentTemplate* d_silent = nullptr;  // zeroed per call: the finished channel block of a silent slot (kernels.h)
     uint32_t* d_work_ctr = nullptr;  // zeroed per call: work counters of the persistent analysis, 8 per pipeline chunk
     uint8_t* zero_region = nullptr;         // one allocation for everything that is zeroed before every call
     size_t zero_bytes = 0;

@@ -63,7 +63,8 @@ struct PendingSlot {
 template <class G>
 __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const AnalyzeParams& prm, const FuseArgs& fa,
                                            const long long idx, const bool flag_byte, const uint32_t flag_value,
-                                           const int tid, PendingSlot* defer STAMP_PARAMS) {
+                                           const int tid, PendingSlot* defer, const uint32_t tmpl_key,
+                                           const uint32_t* plan_stored, const int plan_words STAMP_PARAMS) {
     const uint32_t n = th.n;
     // Optimisation barrier on the thread's coordinates: without it the compiler computes the LDS addresses of the emit
     // phases at kernel entry and keeps them alive (spilled to scratch) through the whole analysis.
@@ -91,6 +92,33 @@ __device__ __forceinline__ void fused_emit(Smem<G>& sh, Thread<G>& th, const Ana
         STAMP(24);
         done = emit_body<G>(sh, th, n, slot, fa.err_flag, [slot](uint8_t** o) { *o = slot; return true; }, tid,
                             LACX_HOOK(prm, 2048u), (uint32_t)fa.slot_stride STAMP_ARGS);
+    }
+    // A silent slot, and nobody has left its finished channel block behind yet (tmpl_key != 0): this workgroup does, if it
+    // is the first to ask.  Plain stores, drained by every wave, the workgroup meets, one release store of the key.
+    if (tmpl_key != 0u && done && sh.payload_bytes <= kSilentBytes) {  // uniform
+        SilentTemplate* t = fa.silent;
+        if (tid == 0) sh.tmpl_state = atomicCAS(&t->state, 0u, 1u);
+        __syncthreads();
+        if (sh.tmpl_state == 0u) {  // uniform
+            const uint32_t nv = (sh.payload_bytes + 15u) >> 4;
+            const uint32_t* tw = sh.xp.o.obits;  // (the whole bitstream is in the one tile: kSilentBytes < the tile)
+            for (uint32_t v = tid; v < nv; v += G::T) {
+                uint4 o;
+                o.x = __builtin_bswap32(tw[4u * v]);
+                o.y = __builtin_bswap32(tw[4u * v + 1u]);
+                o.z = __builtin_bswap32(tw[4u * v + 2u]);
+                o.w = __builtin_bswap32(tw[4u * v + 3u]);
+                reinterpret_cast<uint4*>(t->bytes)[v] = o;
+            }
+            if (tid < plan_words) t->plan[tid] = plan_stored[tid];  // (this thread's own store of a moment ago)
+            if (tid == 0) {
+                t->nbytes = sh.payload_bytes;
+                t->plan_words = (uint32_t)plan_words;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&t->state, tmpl_key, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // publish: the slot was written with write-through (sc1) stores; every storing wave drains them, the workgroup
     // meets, then one lane announces the slot (no release fence needed for sc1 payload: Guideline 16, R1).  A persistent
@@ -303,9 +331,65 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
     bool silent = true;
 #pragma unroll
     for (int w = 0; w < G::T / 64; ++w) silent = silent && sh.wtotF[w] == 0u;  // (uniform)
+    uint32_t tmpl_key = 0;  // != 0: this slot is silent and its finished channel block is to be left in fuse.silent
     if (silent) {
+        // Every silent slot of this length has the same plan and the same bitstream (under the same settings): where an
+        // earlier one has left them behind, this one copies them.
+        uint32_t key = 0;
+        if constexpr (G::T == 1024) {
+            if (fuse.silent && !LACX_HOOK(prm, ~0u)) {  // uniform
+                key = 0x80000000u | (prm.zero_run ? 0x40000000u : 0u) | (prm.partitioning ? 0x20000000u : 0u) | n;
+                if (tid == 0) sh.tmpl_state = __hip_atomic_load(&fuse.silent->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         STAMP(2);
         slot_sync<G>();  // (every wave has read the flags before the scans reuse wtotF)
+        if constexpr (G::T == 1024) {
+            if (key) {  // uniform
+                const uint32_t state = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.tmpl_state);
+                if (state == key) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const SilentTemplate* t = fuse.silent;
+                    const uint32_t nbytes = t->nbytes;
+                    if (tid == 0 && fuse.silent_copies) atomicAdd(fuse.silent_copies, 1u);
+                    if ((uint32_t)tid < t->plan_words) reinterpret_cast<uint32_t*>(plan_out)[tid] = t->plan[tid];
+                    if (fuse_idx >= 0) {  // uniform
+                        if (tid == 0)
+                            rec_store(&fuse.size_rec[fuse_idx], kRecValid | (fuse_flag_value ? kRecMs : 0ull) | (fuse_flag_byte ? kRecFlag : 0ull) |
+                                                                    ((unsigned long long)nbytes + (fuse_flag_byte ? 1u : 0u)));
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        uint8_t* slot = fuse.slots + (unsigned long long)fuse_idx * fuse.slot_stride;
+                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot, 0, (int)fuse.slot_stride, 0x00020000);
+                        const uint32_t nv = (nbytes + 15u) >> 4;
+                        for (uint32_t v = tid; v < nv; v += G::T) {
+                            const uint4 w = reinterpret_cast<const uint4*>(t->bytes)[v];
+                            u32x4 o;
+                            o.x = w.x;
+                            o.y = w.y;
+                            o.z = w.z;
+                            o.w = w.w;
+                            __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (int)(16u * v), 0, 16 /* sc1 */);
+                        }
+                        if (pend) {  // announced behind the next slot's staging barrier, like any other slot
+                            if (tid == 0) {
+                                pend->idx = fuse_idx;
+                                pend->done = 1u;
+                                pend->silent = 0u;
+                            }
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            if (tid == 0) {
+                                fuse.emitted[fuse_idx] = 2u;
+                                rec_store(&fuse.ready_rec[fuse_idx], 1ull);
+                            }
+                        }
+                    }
+                    return;
+                }
+                if (state == 0u && fuse_idx >= 0) tmpl_key = key;
+            }
+        }
         if (tid <= 10) sh.cand_key[tid] = tid == 0 ? 0ull : ~0ull;
     } else {
 #if defined(LACX_STAMPS) && LACX_STAMPS == 3
@@ -713,7 +797,8 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
         reinterpret_cast<uint32_t*>(plan_out)[i] = reinterpret_cast<const uint32_t*>(&sh.plan)[i];
     STAMP(21);
     if constexpr (G::T == 1024) {
-        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid, pend STAMP_ARGS);  // uniform
+        if (fuse_idx >= 0) fused_emit<G>(sh, th, prm, fuse, fuse_idx, fuse_flag_byte, fuse_flag_value, tid, pend, tmpl_key,
+                                        reinterpret_cast<const uint32_t*>(plan_out), plan_words STAMP_ARGS);  // uniform
     }
     STAMP(23);
 #if defined(LACX_STAMPS) && (LACX_STAMPS == 1 || LACX_STAMPS == 3)

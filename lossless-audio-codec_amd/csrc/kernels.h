@@ -97,7 +97,23 @@ inline LaunchSet single_set(const StreamDesc& sd) {
 
 // Where the whole-block analysis kernel writes a channel block's bitstream as soon as its plan is final (slots == null:
 // no fused emit; the bitstream then comes from k_offsets + k_emit alone).
+// The finished channel block of a slot of nothing but zeros (digital silence): its plan and its bitstream are the same
+// for every such slot of the same length under the same settings, so the first workgroup that finishes one leaves them
+// here and every later one copies them instead of analysing and emitting again (k_analyze.hip).  Cleared with the other
+// per-call words; state: 0 empty, 1 being filled, otherwise the key (length and settings) of the slot it holds.
+constexpr uint32_t kSilentBytes = 4096;
+struct alignas(16) SilentTemplate {
+    uint32_t state;
+    uint32_t nbytes;      // bytes of the channel block
+    uint32_t plan_words;  // 32-bit words of the plan record in use
+    uint32_t pad;
+    uint32_t plan[(sizeof(ChannelPlan) + 3) / 4];
+    alignas(16) uint8_t bytes[kSilentBytes];
+};
+
 struct FuseArgs {
+    SilentTemplate* silent = nullptr;      // null: every silent slot is analysed like any other
+    uint32_t* silent_copies = nullptr;     // counts the slots that were copies of it
     uint8_t* slots = nullptr;
     unsigned long long slot_stride = 0;
     uint32_t* emitted = nullptr;            // per stream index: 2 = bitstream is in its slot, 0 = not emitted

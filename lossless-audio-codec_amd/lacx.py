@@ -92,6 +92,8 @@ class Timing(C.Structure):
         ("poll_gap_max_ms", C.c_double),
         ("kernels_done_ms", C.c_double),
         ("enqueue_ms", C.c_double),
+        ("silent_copies", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

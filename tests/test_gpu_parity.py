@@ -769,3 +769,59 @@ def test_batch_regrows_instead_of_failing(gpu, oracle, monkeypatch):
         for (frames, ch, bd, sr, sm, _), (pay, tab), w in zip(specs, res, want):
             assert gpu.lacx.assemble(sr, bd, sm, ch, [(pay.tobytes(), tab.copy())]) == w
         assert be.timing().regrows == 1
+
+
+@pytest.mark.parametrize("template", [True, False], ids=["copies", "every_slot_analysed"])
+def test_silent_blocks_are_copies_of_the_first(gpu, oracle, monkeypatch, template):
+    """Channel blocks of nothing but zeros: the first workgroup that finishes one leaves plan and bitstream behind, later
+    ones copy them (lacx_timing.silent_copies counts them; LACX_NO_SILENT_TEMPLATE analyses every slot).  Same bytes as the
+    oracle either way -- silence between music, a silent side channel, a silent ragged last block (its length differs:
+    never a copy), zero-run coding and partitioning switched off, mono, batch of two formats."""
+    if not template:
+        monkeypatch.setenv("LACX_NO_SILENT_TEMPLATE", "1")
+    rng = np.random.default_rng(2031)
+    B = 16384
+    # (blocks, channels, bit depth, stereo mode, zero_run, partitioning, frames of the ragged tail)
+    cases = [(700, 2, 16, 2, True, True, 777), (420, 2, 24, 0, True, True, 0), (300, 1, 16, 0, True, True, 4000),
+             (330, 2, 16, 1, False, True, 5), (330, 2, 24, 2, True, False, 16383), (300, 2, 16, 2, False, False, 0)]
+    for nblk, ch, bd, sm, zr, part, tail in cases:
+        frames = nblk * B + tail
+        left = np.zeros(frames, np.int32)
+        right = np.zeros(frames, np.int32) if ch == 2 else None
+        music_l, music_r = gpu.synth.synth_pcm(B * 12, 2, bd, 48000, seed=int(rng.integers(1, 10**6)), kind="music", stereo="wide")
+        for j, b in enumerate(sorted(rng.choice(nblk, size=12, replace=False))):  # twelve blocks of music in the silence
+            left[b * B:(b + 1) * B] = music_l[j * B:(j + 1) * B]
+            if ch == 2 and j % 3:  # (every third one with a silent right channel / an all-zero difference)
+                right[b * B:(b + 1) * B] = music_r[j * B:(j + 1) * B] if j % 3 == 1 else left[b * B:(b + 1) * B]
+        left[int(rng.integers(0, frames))] = 1  # and one block that is silent but for one sample
+        enc = gpu.lacx.Encoder(12, sm, 48000, bd, device=0)
+        enc.set_zero_run_enabled(zr)
+        enc.set_partitioning_enabled(part)
+        want = oracle.encode(left, right, 48000, bd, sm, zero_run=zr, partitioning=part, threads=8)
+        for _ in range(2):
+            assert enc.encode(left, right) == want, (nblk, ch, bd, sm, zr, part, tail)
+            copies = enc.timing().silent_copies
+            if template:
+                assert copies >= (nblk - 14) * ch - 300, copies  # all but the ones the 256 workgroups start with
+            else:
+                assert copies == 0
+        enc.close()
+    # two streams of different formats as one job: the silent slots of both are copies of the same block
+    import torch
+
+    specs = [(200 * B + 9, 2, 16, 48000, 2), (150 * B, 1, 24, 96000, 0)]
+    streams, keep, want = [], [], []
+    for frames, ch, bd, sr, sm in specs:
+        left = np.zeros(frames, np.int32)
+        right = np.zeros(frames, np.int32) if ch == 2 else None
+        left[5 * B + 3] = -7
+        inter = gpu.synth.interleave(left, right, bd)
+        d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+        keep.append(d)
+        streams.append((d.data_ptr(), gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24, ch, frames))
+        want.append(oracle.encode(left, right, sr, bd, sm, threads=8))
+    be = gpu.lacx.BatchEncoder([(sr, bd, sm) for (_, _, bd, sr, sm) in specs], device=0)
+    res = be.encode_device(streams, torch.cuda.current_stream().cuda_stream)
+    for (frames, ch, bd, sr, sm), (pay, tab), w in zip(specs, res, want):
+        assert gpu.lacx.assemble(sr, bd, sm, ch, [(pay.tobytes(), tab.copy())]) == w, (frames, ch, bd)
+    assert (be.timing().silent_copies > 0) == template
