@@ -37,6 +37,7 @@ Knobs read_knobs() {
         }
     }
     k.front_halves = !set("LACX_NO_FRONT_HALVES");
+    k.tune.fold_front = !set("LACX_NO_FRONT_FOLD");
     k.lazy_repair = !set("LACX_NO_LAZY_REPAIR");
     k.silent_template = !set("LACX_NO_SILENT_TEMPLATE");
     k.front_stream_split = set("LACX_FRONT_STREAM");  // (measured: slower, see DESIGN 8 -- kept as an experiment switch)
@@ -167,6 +168,7 @@ void free_workspace(lacx_encoder* e) {
     if (e->ws.lpcs) (void)hipFree(e->ws.lpcs);
     if (e->ws.sums) (void)hipFree(e->ws.sums);
     if (e->ws.badidx) (void)hipFree(e->ws.badidx);
+    if (e->ws.front_ctr) (void)hipFree(e->ws.front_ctr);
     if (e->ws.block_off) (void)hipFree(e->ws.block_off);
     if (e->ws.table) (void)hipFree(e->ws.table);
     if (e->ws.stream_pre) (void)hipFree(e->ws.stream_pre);
@@ -191,6 +193,9 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         HIP_TRY(e, hipMalloc((void**)&e->ws.lpcs, slots * sizeof(LpcSet)), "hipMalloc(lpcs)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.sums, (size_t)nblocks * 12 * sizeof(unsigned long long)), "hipMalloc(sums)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.badidx, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(badidx)");
+        // (zeroed once: whoever completes a count puts the word back to zero)
+        HIP_TRY(e, hipMalloc((void**)&e->ws.front_ctr, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(front counters)");
+        HIP_TRY(e, hipMemset(e->ws.front_ctr, 0, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMemset(front counters)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
                 "hipMalloc(block_off)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
@@ -344,6 +349,7 @@ DeviceWorkspace ws_at(const DeviceWorkspace& ws, uint32_t first_block) {
     w.lpcs += s;
     w.sums += (size_t)first_block * 12;
     w.badidx += (size_t)first_block * 2;
+    if (w.front_ctr) w.front_ctr += (size_t)first_block * 2;
     w.table += (size_t)first_block * 2;
     return w;
 }

@@ -827,6 +827,16 @@ __device__ __forceinline__ void analyze_slot(unsigned char* smem_raw, const Anal
 #define LACX_PROBE_WG_WAVES 1
 #endif
 constexpr int kProbeWaves = LACX_PROBE_WG_WAVES;
+// What only the probe class is handed (front_ctr, kernels_internal.h) -- as kernel arguments of the whole-block class the
+// three pointers cost it a spilled VGPR and sixteen spilled SGPRs although it never looks at them.
+template <class G>
+struct TailArgs {};
+template <>
+struct TailArgs<GProbe> {
+    uint32_t* front_ctr;
+    BlockPlan* bplans;
+    uint32_t* need_full_out;
+};
 template <class G>
 __global__ __launch_bounds__(G::T == 64 ? 64 * kProbeWaves : G::T, G::T == 64 ? LACX_PROBE_WAVES : 4) void k_analyze(BatchRef br, int probe_class, uint32_t one_block,
                                                   int which_base, const LpcSet* __restrict__ lpcs,
@@ -834,7 +844,8 @@ __global__ __launch_bounds__(G::T == 64 ? 64 * kProbeWaves : G::T, G::T == 64 ? 
                                                   ChannelPlan* __restrict__ plans,
                                                   unsigned long long* __restrict__ t_first,
                                                   unsigned long long* __restrict__ t_last, FuseArgs fuse,
-                                                  uint32_t* __restrict__ work_ctr, uint32_t total_wg, uint32_t pair_blocks) {
+                                                  uint32_t* __restrict__ work_ctr, uint32_t total_wg, uint32_t pair_blocks,
+                                                  TailArgs<G> tail) {
     extern __shared__ __align__(16) unsigned char smem_all[];
     __shared__ uint32_t s_next;
     __shared__ PendingSlot s_pend;
@@ -952,6 +963,25 @@ __global__ __launch_bounds__(G::T == 64 ? 64 * kProbeWaves : G::T, G::T == 64 ? 
             analyze_slot<G>(smem_raw, prm, n, src, g.start, &lpcs[sidx], &plans[sidx], slot_tid, fuse, fuse_idx, flag_byte,
                             (uint32_t)((slot & 3) >= 2 ? 1u : 0u), persistent ? &s_pend : nullptr);
             if (t_last && tid == 0) atomicMax(t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            if constexpr (G::T == 64) {
+                // Probe class: the last of a block's twelve probe slots makes the block's LR/MS choice (front_ctr,
+                // kernels_internal.h).  The slot's size goes out once more with an agent-scope store and is waited for
+                // in front of the count; the last wave reads the twelve sizes with agent-scope loads (no fences).
+                uint32_t* const front_ctr = tail.front_ctr;
+                if (probe_class && front_ctr) {  // uniform
+                    uint32_t last = 0;
+                    if (tid == 0) {
+                        ChannelPlan* po = &plans[sidx];
+                        agent_store(&po->payload_bytes, reinterpret_cast<Smem<G>*>(smem_raw)->plan.payload_bytes);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        last = atomicAdd(&front_ctr[(size_t)blk * 2 + 1], 1u) == 11u ? 1u : 0u;
+                    }
+                    if (__builtin_amdgcn_readfirstlane((int)last)) {
+                        if (tid == 0) front_ctr[(size_t)blk * 2 + 1] = 0u;
+                        if (tid < 16) decide_probed_block(blk, tid, tail.bplans, tail.need_full_out, plans);
+                    }
+                }
+            }
         }
         if (!persistent) break;
         __syncthreads();  // every wave is done with this slot's LDS image (the emit's tile aliases the next staging area)
@@ -1050,8 +1080,10 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     }
     // the front kernels of the blocks [b0, b0 + cnt) of a one-stream set: ingest, stereo estimate, Levinson, probes, decision
     auto launch_front = [&](const BatchRef& r, const DeviceWorkspace& w, uint32_t cnt, hipStream_t st, bool mark) {
-        hipLaunchKernelGGL(k_ingest, dim3(cnt * 4u), dim3(kIngestThreads), 0, st, r, w.sums, w.badidx, w.acorr);
-        hipLaunchKernelGGL(k_stereo, dim3((cnt + 3) / 4), dim3(64), 0, st, r, w.sums, w.badidx, w.bplans, w.need_probe, w.need_full);
+        uint32_t* fc = tune.fold_front ? w.front_ctr : nullptr;
+        hipLaunchKernelGGL(k_ingest, dim3(cnt * 4u), dim3(kIngestThreads), 0, st, r, w.sums, w.badidx, w.acorr, fc, w.bplans,
+                           w.need_probe, w.need_full);
+        if (!fc) hipLaunchKernelGGL(k_stereo, dim3((cnt + 3) / 4), dim3(64), 0, st, r, w.sums, w.badidx, w.bplans, w.need_probe, w.need_full);
         hipLaunchKernelGGL(k_levinson, dim3((cnt * kSlotsPerBlock + kLevThreads - 1) / kLevThreads), dim3(kLevThreads),
                            sizeof(LevMem), st, r, w.acorr, w.need_probe, w.lpcs);
         if (mark && ev) (void)hipEventRecord(ev[1], st);
@@ -1059,8 +1091,8 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
             static_assert(12 % kProbeWaves == 0, "whole workgroups per block");
             hipLaunchKernelGGL(k_analyze<GProbe>, dim3(cnt * (12u / kProbeWaves)), dim3(GProbe::T * kProbeWaves), sizeof(Smem<GProbe>) * kProbeWaves, st, r, 1, 0u, 0,
                                w.lpcs, w.need_probe, w.plans, (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{},
-                               (uint32_t*)nullptr, 0u, 0u);
-            hipLaunchKernelGGL(k_decide, dim3((cnt + 3) / 4), dim3(64), 0, st, r, 1, w.bplans, w.need_probe, w.need_full, w.plans);
+                               (uint32_t*)nullptr, 0u, 0u, TailArgs<GProbe>{fc, w.bplans, w.need_full});
+            if (!fc) hipLaunchKernelGGL(k_decide, dim3((cnt + 3) / 4), dim3(64), 0, st, r, 1, w.bplans, w.need_probe, w.need_full, w.plans);
         }
     };
     const bool halves = tune.aux_stream && tune.aux_ev[0] && tune.aux_ev[1] && br.table == nullptr && ls.nstreams == 1 && nb >= 1024u;
@@ -1092,6 +1124,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
             w.lpcs += sl;
             w.sums += (size_t)b0 * 12;
             w.badidx += (size_t)b0 * 2;
+            if (w.front_ctr) w.front_ctr += (size_t)b0 * 2;
             return w;
         };
         hipError_t he = hipEventRecord(tune.aux_ev[0], stream);  // behind the memset and whatever the caller queued before
@@ -1129,7 +1162,7 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
     const uint32_t grid = persistent ? (units < pgrid ? units : pgrid) : total_wg;
     hipLaunchKernelGGL(k_analyze<GFull>, dim3(grid), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0, 0u, 0,
                        ws.lpcs, ws.need_full, ws.plans, ws.t_first, ws.t_last, fa, persistent ? ws.work_ctr : (uint32_t*)nullptr,
-                       units, pair_blocks);
+                       units, pair_blocks, TailArgs<GFull>{});
     if (any_both) {  // the 3rd and 4th slots of such a final block: a two-workgroup launch each
         for (uint32_t i = 0; i < ls.nstreams; ++i) {
             const StreamDesc& sd = ls.streams[i];
@@ -1137,7 +1170,8 @@ hipError_t launch_analysis(const LaunchSet& ls, const DeviceWorkspace& ws, hipSt
             if (p.channels == 2 && p.stereo_mode == 2 && p.frames - (uint64_t)(p.num_blocks - 1) * kMaxBlock <= (uint64_t)kFullCompareLimit)
                 hipLaunchKernelGGL(k_analyze<GFull>, dim3(2), dim3(GFull::T), sizeof(Smem<GFull>), stream, br, 0,
                                    sd.first_block + p.num_blocks - 1u, 2, ws.lpcs, ws.need_full, ws.plans,
-                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{}, (uint32_t*)nullptr, 0u, 0u);
+                                   (unsigned long long*)nullptr, (unsigned long long*)nullptr, FuseArgs{}, (uint32_t*)nullptr, 0u, 0u,
+                                   TailArgs<GFull>{});
         }
     }
     if (ev) (void)hipEventRecord(ev[3], stream);

@@ -61,9 +61,36 @@ __device__ __forceinline__ void reduce13(const int64_t* acc, unsigned long long*
     __syncthreads();
 }
 
+__device__ __forceinline__ void stereo_block(const AnalyzeParams& prm, uint32_t blk, uint32_t nb, bool live, int tid,
+                                             const unsigned long long* __restrict__ sums, const uint32_t* __restrict__ badidx,
+                                             BlockPlan* __restrict__ bplans, uint32_t* __restrict__ need_probe,
+                                             uint32_t* __restrict__ need_full);
+
+// The workgroup is done with its (block, channel): count it; the last of the block's four makes the block's stereo estimate
+// (front_ctr, kernels_internal.h).  Thread 0 has written the workgroup's sums / first bad index just before, with
+// agent-scope (write-through) stores: it waits for them, then counts; the last workgroup reads them with agent-scope
+// loads.  No fence on either side (a release fence per workgroup writes the whole L2 back: measured +0.1 ms per kernel).
+__device__ __forceinline__ void ingest_done(uint32_t* __restrict__ front_ctr, unsigned int* s_last, const AnalyzeParams& prm,
+                                            uint32_t blk, uint32_t nb, const unsigned long long* __restrict__ sums,
+                                            const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
+                                            uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
+    if (!front_ctr) return;  // uniform
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_last = atomicAdd(&front_ctr[(size_t)blk * 2], 1u) == 3u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*s_last == 0u || tid >= 64) return;  // (uniform per wave)
+    if (tid == 0) front_ctr[(size_t)blk * 2] = 0u;  // nobody else looks at it any more in this call
+    stereo_block(prm, blk, nb, tid < 16, tid, sums, badidx, bplans, need_probe, need_full);
+}
+
 __global__ __launch_bounds__(kIngestThreads, 5) void k_ingest(BatchRef br, unsigned long long* __restrict__ sums,
                                                            uint32_t* __restrict__ badidx,
-                                                           int64_t* __restrict__ acorr) {
+                                                           int64_t* __restrict__ acorr, uint32_t* __restrict__ front_ctr,
+                                                           BlockPlan* __restrict__ bplans, uint32_t* __restrict__ need_probe,
+                                                           uint32_t* __restrict__ need_full) {
     // One tile = 4096 samples = 16 consecutive samples per thread, kept in LDS as 4-sample groups in four planes:
     // group g of the tile (samples 4g..4g+3) sits in plane g % 4 at index g / 4 (+1: index 0 of a plane is the
     // group carried over from the previous tile).  Thread t writes its groups 4t..4t+3 -- one 16-byte store per
@@ -87,12 +114,13 @@ __global__ __launch_bounds__(kIngestThreads, 5) void k_ingest(BatchRef br, unsig
     // ... unless the container cannot hold an out-of-range value: 16-bit containers, packed 24-bit ones at depth 24
     const bool container_bounds = prm.layout == PCM_INTERLEAVED_I16 || (prm.layout == PCM_INTERLEAVED_I24 && prm.bit_depth == 24);
     const bool validate = ch < 2 && ch < prm.channels && prm.bit_depth != 0 && !container_bounds;
+    const uint32_t nb = block_frames(prm, lblk);
     if (!used && !validate) {  // uniform
-        if (ch < 2 && threadIdx.x == 0) badidx[blk * 2 + ch] = 0xFFFFFFFFu;
+        if (ch < 2 && threadIdx.x == 0) agent_store(&badidx[blk * 2 + ch], 0xFFFFFFFFu);
+        ingest_done(front_ctr, &s_bad, prm, blk, nb, sums, badidx, bplans, need_probe, need_full);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nb = block_frames(prm, lblk);
     const int64_t bstart = (int64_t)lblk * kMaxBlock;
     const SlotSrc src = slot_src(prm, L, R, ch);
     const bool est = prm.channels == 2 && prm.stereo_mode == 2;
@@ -216,31 +244,31 @@ __global__ __launch_bounds__(kIngestThreads, 5) void k_ingest(BatchRef br, unsig
     __syncthreads();
     if (tid == 0) {
         if (est) {
-            sums[(size_t)blk * 12 + ch] = s_sum[0];
-            sums[(size_t)blk * 12 + 4 + ch] = s_sum[1];
-            sums[(size_t)blk * 12 + 8 + ch] = s_sum[2];
+            agent_store(&sums[(size_t)blk * 12 + ch], s_sum[0]);
+            agent_store(&sums[(size_t)blk * 12 + 4 + ch], s_sum[1]);
+            agent_store(&sums[(size_t)blk * 12 + 8 + ch], s_sum[2]);
         }
-        if (validate || ch < 2) badidx[blk * 2 + ch] = s_bad;
+        if (validate || ch < 2) agent_store(&badidx[blk * 2 + ch], s_bad);
     }
+    __syncthreads();  // (thread 0 has read s_bad: the word is reused)
+    ingest_done(front_ctr, &s_bad, prm, blk, nb, sums, badidx, bplans, need_probe, need_full);
 }
 
 // Sixteen lanes per block, four blocks per wave: lanes 0..11 of a block turn one of its 12 proxy sums into bits (one
 // 64-bit division each instead of a chain of twelve), lane 0 of the block decides.
 constexpr int kStereoLanes = 16;
-__global__ __launch_bounds__(64) void k_stereo(BatchRef br, const unsigned long long* __restrict__ sums,
-                                               const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
-                                               uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
-    const int tid = threadIdx.x, sub = tid & (kStereoLanes - 1), grp = tid & ~(kStereoLanes - 1);
-    const uint32_t blk = blockIdx.x * (64 / kStereoLanes) + (uint32_t)(tid / kStereoLanes);
-    const bool live = blk < br.total_blocks;  // every lane stays for the shuffles
-    const StreamDesc sd = stream_of_block(br, live ? blk : 0u);
-    const AnalyzeParams prm = sd.prm;
-    const uint32_t nb = live ? block_frames(prm, blk - sd.first_block) : 0u;
+// The estimate of ONE block by the sixteen lanes of a lane group (tid = lane in the wave; every lane of the wave calls, so
+// that the shuffles find their sources; `live` = this group has a block).
+__device__ __forceinline__ void stereo_block(const AnalyzeParams& prm, uint32_t blk, uint32_t nb, bool live, int tid,
+                                             const unsigned long long* __restrict__ sums, const uint32_t* __restrict__ badidx,
+                                             BlockPlan* __restrict__ bplans, uint32_t* __restrict__ need_probe,
+                                             uint32_t* __restrict__ need_full) {
+    const int sub = tid & (kStereoLanes - 1), grp = tid & ~(kStereoLanes - 1);
     const bool stereo = prm.channels == 2;
     const bool est = stereo && prm.stereo_mode == 2;
     // estimate_channel_proxy_cost: ref lac/encoder.cpp:114-124 -- sums[blk][kind * 4 + channel], kind = raw, diff, anti
     uint64_t bits = 0;
-    if (est && live && sub < 12) bits = approx_rice_bits(sums[(size_t)blk * 12 + sub], nb);
+    if (est && live && sub < 12) bits = approx_rice_bits(agent_load(&sums[(size_t)blk * 12 + sub]), nb);
     auto from = [&](int lane_in_group) {
         const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)bits, grp + lane_in_group, 64);
         const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(bits >> 32), grp + lane_in_group, 64);
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(64) void k_stereo(BatchRef br, const unsigned long 
     bp.uncertain = 0;
     bp.est_ms = 0;
     // first bad sample in the reference's order: the left channel is validated before the right one
-    const uint32_t badl = badidx[blk * 2], badr = stereo ? badidx[blk * 2 + 1] : 0xFFFFFFFFu;
+    const uint32_t badl = agent_load(&badidx[blk * 2]), badr = stereo ? agent_load(&badidx[blk * 2 + 1]) : 0xFFFFFFFFu;
     bp.invalid = (badl != 0xFFFFFFFFu) || (badr != 0xFFFFFFFFu);
     bp.first_bad = (badl != 0xFFFFFFFFu) ? badl : (badr != 0xFFFFFFFFu ? (badr | 0x80000000u) : 0xFFFFFFFFu);
     bp.frames = nb;
@@ -294,6 +322,17 @@ __global__ __launch_bounds__(64) void k_stereo(BatchRef br, const unsigned long 
     bplans[blk] = bp;
     need_probe[blk] = nprobe;
     need_full[blk] = nfull;
+}
+
+__global__ __launch_bounds__(64) void k_stereo(BatchRef br, const unsigned long long* __restrict__ sums,
+                                               const uint32_t* __restrict__ badidx, BlockPlan* __restrict__ bplans,
+                                               uint32_t* __restrict__ need_probe, uint32_t* __restrict__ need_full) {
+    const int tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x * (64 / kStereoLanes) + (uint32_t)(tid / kStereoLanes);
+    const bool live = blk < br.total_blocks;  // every lane stays for the shuffles
+    const StreamDesc sd = stream_of_block(br, live ? blk : 0u);
+    const uint32_t nb = live ? block_frames(sd.prm, blk - sd.first_block) : 0u;
+    stereo_block(sd.prm, blk, nb, live, tid, sums, badidx, bplans, need_probe, need_full);
 }
 
 // ---------------------------------------------------------------------------------------------

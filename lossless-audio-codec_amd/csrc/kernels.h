@@ -26,6 +26,7 @@ struct DeviceWorkspace {
     // ended: its execution span without the time it queued behind other streams (null = not recorded)
     unsigned long long* t_first = nullptr;
     unsigned long long* t_last = nullptr;
+    uint32_t* front_ctr = nullptr; // [num_blocks][2], zero between calls: ingest workgroups / probe slots of the block that are done (kernels_internal.h)
     uint32_t* work_ctr = nullptr;  // a zeroed word: the whole-block analysis runs as persistent workgroups that take their work from it
     // Emit fused into the whole-block analysis kernel (shard-wide arrays, indexed by stream index = block * channels +
     // channel; NOT advanced per pipeline chunk): one fixed-stride staging slot per channel block and a "bitstream is in
@@ -50,6 +51,7 @@ struct LaunchTuning {
     uint32_t persistent_grid = 0;  // workgroups of the persistent whole-block analysis (0 = one per CU)
     int pack_nap = 0;              // the streaming packer's polling pause (0 = default)
     int pack_grid = 0;             // the streaming packer's workgroups (0 = default)
+    bool fold_front = true;        // the block's stereo estimate by its last ingest workgroup, its LR/MS choice by its last probe slot (LACX_NO_FRONT_FOLD: k_stereo / k_decide as kernels)
     bool no_pairs = false;         // persistent analysis: hand every slot out singly (LACX_NO_PAIRS; A/B of the pair units)
     // Front kernels (ingest, stereo, Levinson, probes, decision) on a stream of their own: `stream` of launch_analysis then
     // carries only the whole-block kernel and what follows, ordered behind the front by an event.  Used by the upload
