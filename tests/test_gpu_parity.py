@@ -825,3 +825,36 @@ def test_silent_blocks_are_copies_of_the_first(gpu, oracle, monkeypatch, templat
     for (frames, ch, bd, sr, sm), (pay, tab), w in zip(specs, res, want):
         assert gpu.lacx.assemble(sr, bd, sm, ch, [(pay.tobytes(), tab.copy())]) == w, (frames, ch, bd)
     assert (be.timing().silent_copies > 0) == template
+
+
+@pytest.mark.parametrize("fold", [True, False], ids=["last_workgroup_decides", "k_stereo_and_k_decide"])
+def test_stereo_estimate_and_choice_inside_or_beside_their_producers(gpu, oracle, monkeypatch, fold):
+    """The block's stereo estimate is made by the last of its four ingest workgroups and its LR/MS choice by the last of its
+    twelve probe slots (default), or by the kernels k_stereo / k_decide (LACX_NO_FRONT_FOLD): same bytes, twice in a row on
+    one handle (the counters reset themselves), for auto / forced stereo, mono, a ragged and a small final block, and a
+    shard long enough for the two-halves launch of the front kernels."""
+    if not fold:
+        monkeypatch.setenv("LACX_NO_FRONT_FOLD", "1")
+    cases = [(16384 * 30 + 321, 2, 16, 48000, 2, "mixed"), (16384 * 9 + 4000, 2, 24, 96000, 2, "mixed"),
+             (16384 * 7 + 5, 1, 16, 44100, 0, "music"), (16384 * 6, 2, 16, 48000, 1, "music"),
+             (16384 * 5 + 77, 2, 24, 48000, 0, "noise"), (16384 * 1100 + 9, 2, 16, 48000, 2, "silence")]
+    for frames, ch, bd, sr, sm, kind in cases:
+        left, right = gpu.synth.synth_pcm(frames, ch, bd, sr, seed=91, kind=kind)
+        if kind == "silence":  # (cheap for the oracle; some blocks that are probed in between)
+            l2, r2 = gpu.synth.synth_pcm(16384 * 8, 2, bd, sr, seed=92, kind="noise")
+            left[16384 * 500:16384 * 508] = l2
+            right[16384 * 500:16384 * 508] = r2
+        enc = gpu.lacx.Encoder(12, sm, sr, bd, device=0)
+        want = oracle.encode(left, right, sr, bd, sm, threads=8)
+        for _ in range(2):
+            assert enc.encode(left, right) == want, (fold, frames, ch, bd)
+        import torch
+        if ch == 2:  # and resident in HBM: one chunk, persistent analysis, front kernels in two halves
+            inter = gpu.synth.interleave(left, right, bd)
+            d = torch.from_numpy(inter.view(np.int16) if bd == 16 else inter).cuda()
+            layout = gpu.lacx.PCM_INTERLEAVED_I16 if bd == 16 else gpu.lacx.PCM_INTERLEAVED_I24
+            for _ in range(2):
+                pay, tab = enc.encode_shard_pcm_device_view(d.data_ptr(), layout, 2, frames, 0)
+                got = gpu.lacx.assemble(sr, bd, sm, 2, [(pay.tobytes(), np.array(tab, dtype=np.uint32))])
+                assert got == want, (fold, frames, "device view")
+        enc.close()
