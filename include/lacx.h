@@ -128,6 +128,12 @@ const char* lacx_last_error(const lacx_encoder* enc);
 void lacx_free(void* p);
 void lacx_get_timing(const lacx_encoder* enc, lacx_timing* out);
 
+/* sizeof() of a public struct as this library was built, by name without the prefix ("config", "channel_plan",
+ * "block_plan", "timing", "pcm", "batch_item", "batch_out", "wav_info", "fanout_shard", "fanout_out", "fanout_stats",
+ * "stream_info"); 0 for an unknown name.  A binding that declares the structs itself (ctypes, cgo, JNI) checks its layout
+ * against this before the first call that fills one. */
+uint32_t lacx_sizeof(const char* struct_name);
+
 /* Whole-stream encode of host planar int32 PCM (right == NULL => mono). *out is malloc'd; free with
  * lacx_free. Byte-identical to the reference's LAC::Encoder::encode output. */
 int lacx_encode(lacx_encoder* enc, const int32_t* left, const int32_t* right, uint64_t frames,

@@ -604,4 +604,20 @@ void lacx_get_timing(const lacx_encoder* e, lacx_timing* out) {
     if (e && out) *out = e->timing;
 }
 
+uint32_t lacx_sizeof(const char* name) {
+    if (!name) return 0;
+    const struct {
+        const char* name;
+        size_t size;
+    } table[] = {{"config", sizeof(lacx_config)},           {"channel_plan", sizeof(lacx_channel_plan)},
+                 {"block_plan", sizeof(lacx_block_plan)},   {"timing", sizeof(lacx_timing)},
+                 {"pcm", sizeof(lacx_pcm)},                 {"batch_item", sizeof(lacx_batch_item)},
+                 {"batch_out", sizeof(lacx_batch_out)},     {"wav_info", sizeof(lacx_wav_info)},
+                 {"fanout_shard", sizeof(lacx_fanout_shard)}, {"fanout_out", sizeof(lacx_fanout_out)},
+                 {"fanout_stats", sizeof(lacx_fanout_stats)}, {"stream_info", sizeof(lacx_stream_info)}};
+    for (const auto& t : table)
+        if (std::strcmp(name, t.name) == 0) return (uint32_t)t.size;
+    return 0;
+}
+
 }  // extern "C"

@@ -106,7 +106,7 @@ EXPORTS = (
     "lacx_stream_parse", "lacx_decode", "lacx_decode_last_error", "lacx_encode_batch_device",
     "lacx_encoder_create_multi", "lacx_encoder_lanes", "lacx_fanout_range", "lacx_encode_fanout_resident",
     "lacx_get_fanout_stats", "lacx_get_lane_timing", "lacx_fanout_exchange_note",
-    "lacx_decoder_create", "lacx_decoder_destroy", "lacx_decoder_decode",
+    "lacx_decoder_create", "lacx_decoder_destroy", "lacx_decoder_decode", "lacx_sizeof",
 )
 
 
@@ -156,9 +156,24 @@ def lib():
         L.lacx_encoder_lanes.restype = C.c_uint32
         L.lacx_encoder_lanes.argtypes = [C.c_void_p]
         L.lacx_fanout_range.restype = None
+        # the structs declared in this file against the library's own sizeof(): a layout that has drifted from
+        # include/lacx.h would otherwise show up as memory corruption behind the first call that fills one
+        L.lacx_sizeof.restype = C.c_uint32
+        L.lacx_sizeof.argtypes = [C.c_char_p]
+        for name, cls in abi_structs().items():
+            want = int(L.lacx_sizeof(name.encode()))
+            if want != C.sizeof(cls):
+                raise RuntimeError(f"{path}: sizeof(lacx_{name}) is {want}, the Python binding declares {C.sizeof(cls)} bytes")
         _libs[path] = L
         _lib = L
     return _lib
+
+
+def abi_structs() -> dict:
+    """include/lacx.h struct name (without the prefix) -> the ctypes class that mirrors it."""
+    return {"config": Config, "channel_plan": ChannelPlan, "block_plan": BlockPlan, "timing": Timing, "pcm": Pcm,
+            "batch_item": BatchItem, "batch_out": BatchOut, "wav_info": WavInfo, "fanout_shard": FanoutShard,
+            "fanout_out": FanoutOut, "fanout_stats": FanoutStats, "stream_info": StreamInfo}
 
 
 def device_count() -> int:

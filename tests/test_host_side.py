@@ -233,3 +233,18 @@ def test_hooks_library_is_a_separate_build(pkg):
     hooks = C.CDLL(pkg.lacx.HOOKS_LIB_PATH)
     for name in pkg.lacx.EXPORTS:
         assert hasattr(hooks, name)
+
+
+def test_binding_structs_match_the_library(pkg):
+    """lacx_sizeof: every struct of include/lacx.h that the ctypes binding declares has the size the library was built with
+    (lacx.lib() refuses to load otherwise), an unknown name gives 0, and the header's struct list is the binding's."""
+    import ctypes as C
+
+    L = pkg.lacx.lib()
+    header = open(os.path.join(ROOT, "include", "lacx.h")).read()
+    in_header = set(re.findall(r"^\} lacx_([a-z_]+);", header, flags=re.M))
+    assert in_header == set(pkg.lacx.abi_structs()), in_header ^ set(pkg.lacx.abi_structs())
+    for name, cls in pkg.lacx.abi_structs().items():
+        assert L.lacx_sizeof(name.encode()) == C.sizeof(cls) > 0, name
+    assert L.lacx_sizeof(b"no_such_struct") == 0
+    assert L.lacx_sizeof(None) == 0
