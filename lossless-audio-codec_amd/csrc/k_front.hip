@@ -315,6 +315,12 @@ __device__ __forceinline__ void stereo_block(const AnalyzeParams& prm, uint32_t 
             nfull = bp.est_ms ? 0xCu : 0x3u;
         } else if (nb <= (uint32_t)kFullCompareLimit) {
             nfull = 0xFu;  // encode both, compare sizes (k_decide phase 2)
+        } else if (agent_load(&sums[(size_t)blk * 12]) == 0ull && agent_load(&sums[(size_t)blk * 12 + 1]) == 0ull) {
+            // Both raw sums are zero: every sample of the block is zero (digital silence), so are mid and side, the
+            // twelve probe encodes are twelve times the same bytes, the comparison ties and left/right stays
+            // (ref lac/encoder.cpp:347-353: mid/side only when strictly smaller).  No probes, no Levinson for them.
+            nfull = 0x3u;
+            bp.choose_ms = 0;
         } else {
             nprobe = 0xFFF0u;  // 12 probe slots; the whole-block pair is picked by k_decide phase 1
         }
