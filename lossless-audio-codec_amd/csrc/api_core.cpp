@@ -196,6 +196,8 @@ int ensure_workspace(lacx_encoder* e, uint32_t nblocks) {
         // (zeroed once: whoever completes a count puts the word back to zero)
         HIP_TRY(e, hipMalloc((void**)&e->ws.front_ctr, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(front counters)");
         HIP_TRY(e, hipMemset(e->ws.front_ctr, 0, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMemset(front counters)");
+        // (the null stream's memset is not ordered against this encoder's non-blocking streams: wait for it here, once)
+        HIP_TRY(e, hipStreamSynchronize(nullptr), "hipStreamSynchronize");
         HIP_TRY(e, hipMalloc((void**)&e->ws.block_off, ((size_t)nblocks + kMaxChunks + 1) * sizeof(unsigned long long)),
                 "hipMalloc(block_off)");
         HIP_TRY(e, hipMalloc((void**)&e->ws.table, (size_t)nblocks * 2 * sizeof(uint32_t)), "hipMalloc(table)");
